@@ -1,0 +1,1621 @@
+// bioem_hip.hip -- MI355X (gfx950 / CDNA4) implementation of the BioEM compare path behind the
+// C ABI of include/bioem_hip.h.  Hand-written HIP, wave64, no vendor FFT/BLAS on the hot path.
+//
+// Hot path (replaces bioem_cuda::compareRefMaps + cuFFT, /root/reference/bioem_cuda.cu:527-684, and the
+// host-side createProjection / createConvolutedProjectionMap, /root/reference/bioem.cpp:1604-1923):
+//
+//   k_project        model points -> real-space projection (double atomics), one launch per batch
+//   k_dft_rows/cols  r2c of the projections (exact DFT, double accumulation; not on the critical path)
+//   k_convolve       proj * conj(CTF) -> conv spectra in the comparison layout, sumC, sumsquareC
+//   k_compare_fast   one WAVE per (particle, orientation*CTF) comparison:
+//                      spectrum product -> pruned inverse 2-D transform -> displacement-window log posterior
+//                      -> wave log-sum-exp/arg-max partial.  The length-N inverse along kx is split as
+//                      N = N1*32: N1 register-resident 32-point FFTs per frequency column (lane = column),
+//                      recombined only for the 2*maxD+1 displacements that are consumed (output pruning),
+//                      so no radix-7 butterfly is ever needed for N = 224.  The transform along ky is a
+//                      pruned real DFT evaluated from LDS for the displacement window only.
+//   k_compare_generic  same maths for any N / maxD (direct pruned DFT), correctness path
+//   k_fold           folds the per-(particle, orientation*CTF) partials into the probability block in the
+//                      reference's (orientation, CTF) order (bioem_algorithm.h:96-123, bioem.cpp:1527-1600)
+//
+// Numerics: float expressions that the reference evaluates in float are written in the same order and the
+// file is compiled with -ffp-contract=off (FMAs only where fmaf() is spelled out).  Sums that the reference
+// accumulates sequentially in float (sumsquareC, particle sums) are accumulated in the same order.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "bioem_hip.h"
+
+#define MIN_PROB (-999999.)
+
+namespace
+{
+
+struct Partial
+{
+  double sumExp;
+  float best;
+  int id;
+  float value;
+  int pad;
+};
+
+typedef bioem_hip_param_device PD;
+
+// ------------------------------------------------------------------------------------------------
+// error handling
+// ------------------------------------------------------------------------------------------------
+struct HipErr
+{
+  std::string msg;
+};
+
+#define HIP_CHECK(h, expr)                                                                                         \
+  do                                                                                                               \
+  {                                                                                                                \
+    hipError_t e_ = (expr);                                                                                        \
+    if (e_ != hipSuccess)                                                                                          \
+    {                                                                                                              \
+      char buf_[512];                                                                                              \
+      snprintf(buf_, sizeof(buf_), "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__);     \
+      (h)->err = buf_;                                                                                             \
+      return 1;                                                                                                    \
+    }                                                                                                              \
+  } while (0)
+
+} // namespace
+
+struct bioem_hip_ctx
+{
+  int device = 0;
+  hipStream_t stream = nullptr;
+  PD pd;
+  int nMaps = 0, nAngles = 0, nCTF = 0, algo = 1;
+  int N = 0, H = 0, M = 0;
+  int fast = 0, N1 = 0, winD = 0; // winD = template window half width used by the fast kernel
+  int nd = 0;                     // displacements per axis
+  std::vector<int> disp;
+  int OB = 0;     // orientations per batch of the native path
+  int maxOC = 0;  // capacity of conv/param/partial buffers in (orientation*CTF) units
+  int chunkB = 0; // images per DFT chunk
+
+  float2 *dRef = nullptr;
+  float *dSumRef = nullptr, *dSumsqRef = nullptr;
+  float2 *dCTF = nullptr;
+  float *dCtfParam = nullptr;
+  bioem_hip_model_point *dPts = nullptr;
+  int nPts = 0;
+  float NormDen = 0, pixelSize = 0;
+  int shiftX = 0, shiftY = 0;
+  float4 *dAngles = nullptr;
+  int nAnglesUp = 0, isQuat = 1;
+  float2 *dTw = nullptr;   // N+1 entries exp(+2 pi i k/N), float
+  double2 *dTwD = nullptr; // N entries, double
+  int *dDisp = nullptr;
+
+  double *dProjReal = nullptr; // [chunkB][N*N]
+  double *dTempDen = nullptr;  // [chunkB]
+  double2 *dRowSpec = nullptr; // [chunkB][N][H]
+  float2 *dSpecRef = nullptr;  // [chunkB][M] reference layout
+  float *dScratch = nullptr;   // [maxOC][M] ordered |X|^2 terms for sumsquareC
+  float2 *dConv = nullptr;     // [maxOC][M] comparison layout
+  bioem_hip_param5 *dParams = nullptr;
+  Partial *dPartials = nullptr; // [nMaps][maxOC]
+  unsigned char *dProb = nullptr;
+  size_t probBytes = 0;
+
+  // compat entry staging
+  float2 *hStage = nullptr;
+  float2 *dStage = nullptr;
+  bioem_hip_param5 *hStageP = nullptr;
+  int stageConv = 0;
+  hipEvent_t slotEvent[2] = {nullptr, nullptr};
+  bool slotPending[2] = {false, false};
+
+  // timing
+  std::vector<hipEvent_t> evPool;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> evPending;
+  double compareMs = 0;
+  long long launches = 0, comparisons = 0;
+
+  std::string err;
+};
+
+namespace
+{
+
+// ------------------------------------------------------------------------------------------------
+// layout of a half spectrum used by the comparison kernels
+//   fast   : kx = N1*k2 + k1  ->  float2 index ((k1*16 + (k2>>1))*H + ky)*2 + (k2&1)
+//            (lane = ky reads 16 B = two k2 of one k1 -> fully coalesced dwordx4, and the 32 inputs
+//             of one register FFT arrive as 16 such loads)
+//   generic: reference layout kx*H + ky
+// ------------------------------------------------------------------------------------------------
+__host__ __device__ inline size_t layout_index(int fast, int N1, int H, int kx, int ky)
+{
+  if (!fast)
+    return (size_t) kx * H + ky;
+  const int k1 = kx % N1, k2 = kx / N1;
+  return ((size_t) (k1 * 16 + (k2 >> 1)) * H + ky) * 2 + (k2 & 1);
+}
+
+__global__ void k_reorder(const float2 *__restrict__ src, float2 *__restrict__ dst, int nImg, int N, int H, int fast,
+                          int N1)
+{
+  const size_t M = (size_t) N * H;
+  const size_t total = M * nImg;
+  for (size_t e = (size_t) blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t) gridDim.x * blockDim.x)
+  {
+    const size_t img = e / M;
+    const int r = (int) (e - img * M);
+    const int kx = r / H, ky = r - kx * H;
+    dst[img * M + layout_index(fast, N1, H, kx, ky)] = src[e];
+  }
+}
+
+__global__ void k_unreorder(const float2 *__restrict__ src, float2 *__restrict__ dst, int nImg, int N, int H,
+                            int fast, int N1)
+{
+  const size_t M = (size_t) N * H;
+  const size_t total = M * nImg;
+  for (size_t e = (size_t) blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t) gridDim.x * blockDim.x)
+  {
+    const size_t img = e / M;
+    const int r = (int) (e - img * M);
+    const int kx = r / H, ky = r - kx * H;
+    dst[e] = src[img * M + layout_index(fast, N1, H, kx, ky)];
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// projection: bioem.cpp:1604-1818 (rotation, point / sphere splat, tempden)
+// one thread per model point, blockIdx.y = orientation inside the batch
+// ------------------------------------------------------------------------------------------------
+__global__ void k_project(const bioem_hip_model_point *__restrict__ pts, int nPts, const float4 *__restrict__ angles,
+                          int o0, int isQuat, int N, float pixelSize, int shiftX, int shiftY,
+                          double *__restrict__ proj, double *__restrict__ tempden)
+{
+  const int ob = blockIdx.y;
+  const float4 a = angles[o0 + ob];
+  float rotmat[3][3];
+  if (isQuat)
+  {
+    const float q0 = a.x, q1 = a.y, q2 = a.z, q3 = a.w; // bioem.cpp:1632-1646
+    rotmat[0][0] = 1 - 2 * q1 * q1 - 2 * q2 * q2;
+    rotmat[1][0] = 2 * (q0 * q1 - q2 * q3);
+    rotmat[2][0] = 2 * (q0 * q2 + q1 * q3);
+    rotmat[0][1] = 2 * (q0 * q1 + q2 * q3);
+    rotmat[1][1] = 1 - 2 * q0 * q0 - 2 * q2 * q2;
+    rotmat[2][1] = 2 * (q1 * q2 - q0 * q3);
+    rotmat[0][2] = 2 * (q0 * q2 - q1 * q3);
+    rotmat[1][2] = 2 * (q1 * q2 + q0 * q3);
+    rotmat[2][2] = 1 - 2 * q0 * q0 - 2 * q1 * q1;
+  }
+  else
+  {
+    const float alpha = a.x, beta = a.y, gam = a.z; // bioem.cpp:1653-1672
+    const float ca = cosf(alpha), sa = sinf(alpha), cb = cosf(beta), sb = sinf(beta), cg = cosf(gam), sg = sinf(gam);
+    rotmat[0][0] = cg * ca - cb * sa * sg;
+    rotmat[0][1] = cg * sa + cb * ca * sg;
+    rotmat[0][2] = sg * sb;
+    rotmat[1][0] = -sg * ca - cb * sa * cg;
+    rotmat[1][1] = -sg * sa + cb * ca * cg;
+    rotmat[1][2] = cg * sb;
+    rotmat[2][0] = sb * sa;
+    rotmat[2][1] = -sb * ca;
+    rotmat[2][2] = cb;
+  }
+  double td = 0.;
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  double *map = proj + (size_t) ob * N * N;
+  if (n < nPts)
+  {
+    const bioem_hip_model_point p = pts[n];
+    float rp[3] = {0.f, 0.f, 0.f};
+    for (int k = 0; k < 3; k++)
+      for (int j = 0; j < 3; j++)
+        rp[k] += rotmat[k][j] * p.pos[j];
+    const float radius = p.radius, density = p.density;
+    if (radius <= pixelSize)
+    {
+      const int i = (int) floorf(rp[0] / pixelSize + (float) N / 2.0f + 0.5f);
+      const int j = (int) floorf(rp[1] / pixelSize + (float) N / 2.0f + 0.5f);
+      if (!(i < 0 || j < 0 || i >= N || j >= N))
+      {
+        atomicAdd(&map[i * N + j], (double) density);
+        td += (double) density;
+      }
+    }
+    else
+    {
+      const int i = (int) floorf(rp[0] / pixelSize + (float) N / 2.0f + 0.5f) - shiftX;
+      const int j = (int) floorf(rp[1] / pixelSize + (float) N / 2.0f + 0.5f) - shiftY;
+      const int irad = (int) (radius / pixelSize) + 1;
+      const float rad2 = radius * radius;
+      if (!(i < irad || j < irad || i >= N - irad || j >= N - irad))
+      {
+        for (int ii = i - irad; ii < i + irad + 1; ii++)
+          for (int jj = j - irad; jj < j + irad + 1; jj++)
+          {
+            const float dist = ((float) (ii - i) * (ii - i) + (jj - j) * (jj - j)) * pixelSize * pixelSize;
+            if (dist < rad2)
+            {
+              const double w = (double) (pixelSize * pixelSize * 2 * sqrtf(rad2 - dist) * density * 3) /
+                               (4 * M_PI * radius * rad2);
+              atomicAdd(&map[ii * N + jj], w);
+              td += w;
+            }
+          }
+      }
+    }
+  }
+  // block reduction of tempden
+  __shared__ double red[256];
+  red[threadIdx.x] = td;
+  __syncthreads();
+  for (int s = blockDim.x / 2; s > 0; s >>= 1)
+  {
+    if ((int) threadIdx.x < s)
+      red[threadIdx.x] += red[threadIdx.x + s];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0 && red[0] != 0.)
+    atomicAdd(&tempden[ob], red[0]);
+}
+
+// ------------------------------------------------------------------------------------------------
+// r2c as two exact-DFT passes with double accumulation (FFTW forward convention, unnormalised).
+// rows: src is either the double projection map scaled by NormDen/tempden in float (bioem.cpp:1808-1818)
+//       or float particle maps.
+// ------------------------------------------------------------------------------------------------
+__global__ void k_dft_rows(const double *__restrict__ srcD, const float *__restrict__ srcF,
+                           const double *__restrict__ tempden, float NormDen, int N, int H,
+                           const double2 *__restrict__ twD, double2 *__restrict__ rowspec)
+{
+  extern __shared__ double srow[];
+  const int i = blockIdx.x, b = blockIdx.y;
+  float ratio = 1.f;
+  if (srcD)
+    ratio = NormDen / (float) tempden[b];
+  for (int j = threadIdx.x; j < N; j += blockDim.x)
+  {
+    float v;
+    if (srcD)
+    {
+      v = (float) srcD[((size_t) b * N + i) * N + j];
+      v = v * ratio;
+    }
+    else
+      v = srcF[((size_t) b * N + i) * N + j];
+    srow[j] = (double) v;
+  }
+  __syncthreads();
+  for (int k = threadIdx.x; k < H; k += blockDim.x)
+  {
+    double ar = 0., ai = 0.;
+    int idx = 0;
+    for (int j = 0; j < N; j++)
+    {
+      const double2 w = twD[idx];
+      ar = fma(srow[j], w.x, ar);
+      ai = fma(-srow[j], w.y, ai); // forward: e^{-i}
+      idx += k;
+      if (idx >= N)
+        idx -= N;
+    }
+    rowspec[((size_t) b * N + i) * H + k] = make_double2(ar, ai);
+  }
+}
+
+__global__ void k_dft_cols(const double2 *__restrict__ rowspec, int N, int H, const double2 *__restrict__ twD,
+                           float2 *__restrict__ out)
+{
+  extern __shared__ double srow[];
+  double2 *col = (double2 *) srow;
+  const int k = blockIdx.x, b = blockIdx.y;
+  for (int i = threadIdx.x; i < N; i += blockDim.x)
+    col[i] = rowspec[((size_t) b * N + i) * H + k];
+  __syncthreads();
+  for (int u = threadIdx.x; u < N; u += blockDim.x)
+  {
+    double ar = 0., ai = 0.;
+    int idx = 0;
+    for (int i = 0; i < N; i++)
+    {
+      const double2 w = twD[idx]; // multiply by conj(w)
+      ar = fma(col[i].x, w.x, ar);
+      ar = fma(col[i].y, w.y, ar);
+      ai = fma(col[i].y, w.x, ai);
+      ai = fma(-col[i].x, w.y, ai);
+      idx += u;
+      if (idx >= N)
+        idx -= N;
+    }
+    out[(size_t) b * N * H + (size_t) u * H + k] = make_float2((float) ar, (float) ai);
+  }
+}
+
+// particle sums, bioem.cpp:2087-2107: sequential float accumulation in row-major order.
+__global__ void k_map_sums(const float *__restrict__ maps, int NN, float *__restrict__ sum, float *__restrict__ sumsq)
+{
+  __shared__ float buf[4096];
+  const float *m = maps + (size_t) blockIdx.x * NN;
+  float s = 0.0f, s2 = 0.0f;
+  for (int base = 0; base < NN; base += 4096)
+  {
+    const int cnt = min(4096, NN - base);
+    for (int t = threadIdx.x; t < cnt; t += blockDim.x)
+      buf[t] = m[base + t];
+    __syncthreads();
+    if (threadIdx.x == 0)
+      for (int t = 0; t < cnt; t++)
+      {
+        s += buf[t];
+        s2 += buf[t] * buf[t];
+      }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0)
+  {
+    sum[blockIdx.x] = s;
+    sumsq[blockIdx.x] = s2;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// convolution: bioem.cpp:1855-1923.  grid (nCTF, nOrientInBatch).
+// sumsquareC is accumulated sequentially in float in the reference's order (rows; inside a row the
+// interior columns doubled, then column 0, then column N/2 for even N): the terms are produced in
+// parallel into `scratch` in that order and summed by one lane.
+// ------------------------------------------------------------------------------------------------
+__global__ void k_convolve(const float2 *__restrict__ proj, const float2 *__restrict__ ctf,
+                           const float *__restrict__ ctfParam, int N, int H, int fast, int N1, int nCTF,
+                           float2 *__restrict__ conv, float *__restrict__ scratch,
+                           bioem_hip_param5 *__restrict__ params)
+{
+  __shared__ float buf[4096];
+  const int c = blockIdx.x, ob = blockIdx.y;
+  const int oc = ob * nCTF + c;
+  const int M = N * H;
+  const float2 *P = proj + (size_t) ob * M;
+  const float2 *K = ctf + (size_t) c * M;
+  float2 *O = conv + (size_t) oc * M;
+  float *S = scratch + (size_t) oc * M;
+  const int even = ((N & 1) == 0);
+  const int jend = even ? H - 1 : H;
+  float sumC = 0.f;
+  for (int e = threadIdx.x; e < M; e += blockDim.x)
+  {
+    const int i = e / H, j = e - i * H;
+    const float2 p = P[e], k = K[e];
+    float2 o;
+    o.x = (p.x * k.x + p.y * k.y);
+    o.y = (p.y * k.x - p.x * k.y);
+    O[layout_index(fast, N1, H, i, j)] = o;
+    const float t = o.x * o.x + o.y * o.y;
+    // position of this term in the reference's summation order
+    int pos;
+    if (j >= 1 && j < jend)
+      pos = i * H + (j - 1);
+    else if (j == 0)
+      pos = i * H + (jend - 1);
+    else
+      pos = i * H + jend; // j == H-1, even N
+    S[pos] = (j >= 1 && j < jend) ? t * 2 : t;
+    if (e == 0)
+      sumC = o.x;
+  }
+  __syncthreads();
+  __threadfence_block();
+  float ss = 0.f;
+  for (int base = 0; base < M; base += 4096)
+  {
+    const int cnt = min(4096, M - base);
+    for (int t = threadIdx.x; t < cnt; t += blockDim.x)
+      buf[t] = S[base + t];
+    __syncthreads();
+    if (threadIdx.x == 0)
+      for (int t = 0; t < cnt; t++)
+        ss += buf[t];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0)
+  {
+    bioem_hip_param5 r;
+    r.amp = ctfParam[3 * c + 0];
+    r.pha = ctfParam[3 * c + 1];
+    r.env = ctfParam[3 * c + 2];
+    r.sumC = sumC;
+    const float norm2 = (float) (N * N);
+    r.sumsquareC = ss / norm2;
+    params[oc] = r;
+  }
+}
+
+// sums only (compat entry supplies conv spectra but we never trust host params blindly: they are used as given)
+
+// ------------------------------------------------------------------------------------------------
+// log posterior, bioem_algorithm.h:18-70.  constPart = second log term, priorPart = Gaussian priors:
+// both depend on the (orientation, CTF) pair only and are hoisted; the summation order
+// (t1 + t2) - prior of the reference is kept.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void logpro_consts(const PD &pd, const bioem_hip_param5 &q, double &t2, double &prior)
+{
+  const float Np = pd.Ntotpi;
+  const double ForLogProb = (double) (q.sumsquareC * Np - q.sumC * q.sumC);
+  t2 = ((double) Np * 0.5 - 2) * log((double) (Np - 2) * ForLogProb);
+  const float amp = q.amp, pha = q.pha, env = q.env;
+  if (!pd.tousepsf)
+  {
+    prior = (double) (env * env) / 2. / (double) pd.sigmaPriorbctf / (double) pd.sigmaPriorbctf -
+            (double) ((pha - pd.Priordefcent) * (pha - pd.Priordefcent)) / 2. / (double) pd.sigmaPriordefo /
+                (double) pd.sigmaPriordefo -
+            (double) ((amp - pd.Priorampcent) * (amp - pd.Priorampcent)) / 2. / (double) pd.sigmaPrioramp /
+                (double) pd.sigmaPrioramp;
+  }
+  else
+  {
+    const double envF = 4. * M_PI * M_PI * (double) env / (double) (env * env + pha * pha);
+    const double phaF = 4. * M_PI * M_PI * (double) pha / (double) (env * env + pha * pha);
+    const double dp = phaF - (double) pd.Priordefcent;
+    prior = envF * envF / 2. / (double) pd.sigmaPriorbctf / (double) pd.sigmaPriorbctf -
+            dp * dp / 2. / (double) pd.sigmaPriordefo / (double) pd.sigmaPriordefo -
+            (double) ((amp - pd.Priorampcent) * (amp - pd.Priorampcent)) / 2. / (double) pd.sigmaPrioramp /
+                (double) pd.sigmaPrioramp;
+  }
+}
+
+__device__ __forceinline__ double logpro_eval(const PD &pd, const bioem_hip_param5 &q, float cc, float sumref,
+                                              float sumsqref, double t2, double prior)
+{
+  const float Np = pd.Ntotpi;
+  const float sum = q.sumC, sumsq = q.sumsquareC;
+  const float firstele_f = Np * (sumsqref * sumsq - cc * cc) + 2 * sumref * sum * cc - sumsqref * sum * sum -
+                           sumref * sumref * sumsq;
+  double logpro = (double) (3 - Np) * 0.5 * log((double) firstele_f) + t2;
+  logpro -= prior;
+  return logpro;
+}
+
+// online log-sum-exp state of one lane / wave
+struct Lse
+{
+  float m;   // best logpro (narrowed to float as the reference does)
+  double s;  // sum exp(logpro - m)
+  int id;    // rank of the best displacement in the reference's visiting order
+  float val; // cross-correlation value at the best displacement
+};
+
+__device__ __forceinline__ void lse_init(Lse &L)
+{
+  L.m = -INFINITY;
+  L.s = 0.;
+  L.id = 0x7fffffff;
+  L.val = 0.f;
+}
+
+// algo 1: logpro narrowed to float before use (bioem_algorithm.h:84); algo 2: double in the exponent,
+// float for the running best (bioem.cpp:1470,1500-1507)
+__device__ __forceinline__ void lse_push(Lse &L, double lp, int id, float val, int algo)
+{
+  const float lpf = (float) lp;
+  const double lpe = (algo == 1) ? (double) lpf : lp;
+  if (L.m < lpf)
+  {
+    L.s = (L.m == -INFINITY) ? 0. : L.s * exp((double) L.m - (double) lpf);
+    L.m = lpf;
+    L.id = id;
+    L.val = val;
+  }
+  L.s += exp(lpe - (double) L.m);
+}
+
+__device__ __forceinline__ void lse_merge(Lse &L, float m2, double s2, int id2, float val2)
+{
+  if (m2 > L.m || (m2 == L.m && id2 < L.id))
+  {
+    const double sc = (L.m == -INFINITY) ? 0. : L.s * exp((double) L.m - (double) m2);
+    L.s = sc + s2;
+    L.m = m2;
+    L.id = id2;
+    L.val = val2;
+  }
+  else
+  {
+    const double sc = (m2 == -INFINITY) ? 0. : s2 * exp((double) m2 - (double) L.m);
+    L.s += sc;
+  }
+}
+
+__device__ __forceinline__ void lse_wave_reduce(Lse &L)
+{
+  for (int off = 32; off > 0; off >>= 1)
+  {
+    const float m2 = __shfl_xor(L.m, off);
+    const double s2 = __shfl_xor(L.s, off);
+    const int id2 = __shfl_xor(L.id, off);
+    const float v2 = __shfl_xor(L.val, off);
+    lse_merge(L, m2, s2, id2, v2);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// 32-point inverse FFT in registers: radix-2 decimation in frequency, sign +, output bit-reversed.
+// ------------------------------------------------------------------------------------------------
+__device__ constexpr float COS32[16] = {1.0f,
+                                        0.98078528040323044913f,
+                                        0.92387953251128675613f,
+                                        0.83146961230254523708f,
+                                        0.70710678118654752440f,
+                                        0.55557023301960222474f,
+                                        0.38268343236508977173f,
+                                        0.19509032201612826785f,
+                                        0.0f,
+                                        -0.19509032201612826785f,
+                                        -0.38268343236508977173f,
+                                        -0.55557023301960222474f,
+                                        -0.70710678118654752440f,
+                                        -0.83146961230254523708f,
+                                        -0.92387953251128675613f,
+                                        -0.98078528040323044913f};
+__device__ constexpr float SIN32[16] = {0.0f,
+                                        0.19509032201612826785f,
+                                        0.38268343236508977173f,
+                                        0.55557023301960222474f,
+                                        0.70710678118654752440f,
+                                        0.83146961230254523708f,
+                                        0.92387953251128675613f,
+                                        0.98078528040323044913f,
+                                        1.0f,
+                                        0.98078528040323044913f,
+                                        0.92387953251128675613f,
+                                        0.83146961230254523708f,
+                                        0.70710678118654752440f,
+                                        0.55557023301960222474f,
+                                        0.38268343236508977173f,
+                                        0.19509032201612826785f};
+
+__host__ __device__ constexpr int bitrev5(int n)
+{
+  return ((n & 1) << 4) | ((n & 2) << 2) | (n & 4) | ((n & 8) >> 2) | ((n & 16) >> 4);
+}
+
+__device__ __forceinline__ void fft32_inverse(float (&xr)[32], float (&xi)[32])
+{
+#pragma unroll
+  for (int s = 0; s < 5; s++)
+  {
+    const int m = 16 >> s;
+#pragma unroll
+    for (int b = 0; b < 32; b += 2 * m)
+    {
+#pragma unroll
+      for (int j = 0; j < m; j++)
+      {
+        const int i0 = b + j, i1 = b + j + m;
+        const int t = j << s;
+        const float ar = xr[i0], ai = xi[i0], br = xr[i1], bi = xi[i1];
+        xr[i0] = ar + br;
+        xi[i0] = ai + bi;
+        const float dr = ar - br, di = ai - bi;
+        if (t == 0)
+        {
+          xr[i1] = dr;
+          xi[i1] = di;
+        }
+        else if (t == 8)
+        {
+          xr[i1] = -di;
+          xi[i1] = dr;
+        }
+        else
+        {
+          const float c = COS32[t], sn = SIN32[t];
+          xr[i1] = fmaf(dr, c, -(di * sn));
+          xi[i1] = fmaf(dr, sn, di * c);
+        }
+      }
+    }
+  }
+}
+
+struct CompareArgs
+{
+  const float2 *ref;  // [nMaps][M] comparison layout
+  const float2 *conv; // [nOC][M]
+  const bioem_hip_param5 *params;
+  const float *sumRef, *sumsqRef;
+  const float2 *tw; // N+1
+  const int *disp;  // nd
+  Partial *partials; // [nMaps][ldPart]
+  int ldPart;
+  int N, H, N1, nd, maxD, nOC, nMaps, algo;
+  PD pd;
+};
+
+// Evaluate the displacement window from the column transforms T (LDS, [row = dx + WD][Hs] float2, already
+// weighted by 1 or 2 per column) and reduce to this wave's partial.
+// lane = (iy, group); a group owns up to NR consecutive displacement rows, so each twiddle E[ky*dy] read
+// from LDS feeds NR accumulators.
+template <int WD, int NR>
+__device__ __forceinline__ void window_eval(const CompareArgs &a, const float2 *Tl, int Hs, const float2 *twl,
+                                            const int *displ, const bioem_hip_param5 &q, float sumref,
+                                            float sumsqref, Lse &L)
+{
+  const int lane = threadIdx.x & 63;
+  const int nd = a.nd, N = a.N;
+  const int G = 64 / nd;
+  const int nr = (nd + G - 1) / G;
+  const int iy = lane % nd, grp = lane / nd;
+  const bool active = grp < G;
+  const int dy = displ[iy];
+  const int step = dy < 0 ? dy + N : dy;
+  float acc[NR];
+  int rowoff[NR];
+#pragma unroll
+  for (int r = 0; r < NR; r++)
+  {
+    acc[r] = 0.f;
+    int ix = grp * nr + r;
+    if (ix >= nd)
+      ix = nd - 1;
+    rowoff[r] = (displ[ix] + WD) * Hs;
+  }
+  int idx = 0;
+  const int H2 = Hs >> 1;
+  for (int kp = 0; kp < H2; kp++)
+  {
+    const float2 w0 = twl[idx];
+    idx += step;
+    if (idx >= N)
+      idx -= N;
+    const float2 w1 = twl[idx];
+    idx += step;
+    if (idx >= N)
+      idx -= N;
+#pragma unroll
+    for (int r = 0; r < NR; r++)
+    {
+      if (r < nr)
+      {
+        const float4 t = *reinterpret_cast<const float4 *>(&Tl[rowoff[r] + 2 * kp]);
+        acc[r] = fmaf(t.x, w0.x, acc[r]);
+        acc[r] = fmaf(-t.y, w0.y, acc[r]);
+        acc[r] = fmaf(t.z, w1.x, acc[r]);
+        acc[r] = fmaf(-t.w, w1.y, acc[r]);
+      }
+    }
+  }
+  double t2, prior;
+  logpro_consts(a.pd, q, t2, prior);
+  const float nn = (float) (N * N);
+#pragma unroll
+  for (int r = 0; r < NR; r++)
+  {
+    const int ix = grp * nr + r;
+    if (r < nr && active && ix < nd)
+    {
+      const float value = acc[r] / nn;
+      const double lp = logpro_eval(a.pd, q, value, sumref, sumsqref, t2, prior);
+      lse_push(L, lp, ix * nd + iy, value, a.algo);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// fast comparison kernel: N = 32*N1, 2*maxD+1 <= 2*WD+1 <= 31.
+// block = 4 waves = 4 consecutive (orientation*CTF) indices of ONE particle (the particle columns are then
+// served to waves 1..3 from L1); blockIdx.x = ocGroup * nMaps + particle, so concurrently resident blocks
+// share the same 4 conv spectra in L2.
+// ------------------------------------------------------------------------------------------------
+template <int WD>
+__global__ __launch_bounds__(256) void k_compare_fast(const CompareArgs a)
+{
+  constexpr int NW = 2 * WD + 1;
+  constexpr int NR = (WD <= 10) ? 7 : 16;
+  extern __shared__ __align__(16) unsigned char smem[];
+  const int N = a.N, H = a.H, N1 = a.N1;
+  const int Hs = (H + 1) & ~1;
+  float2 *twl = reinterpret_cast<float2 *>(smem);                        // N+1 (+pad)
+  int *displ = reinterpret_cast<int *>(smem + (size_t) ((N + 2) & ~1) * 8); // nd ints (64 reserved)
+  float2 *Tall = reinterpret_cast<float2 *>(smem + (size_t) ((N + 2) & ~1) * 8 + 256);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  float2 *Tl = Tall + (size_t) wave * NW * Hs;
+
+  for (int t = threadIdx.x; t <= N; t += blockDim.x)
+    twl[t] = a.tw[t];
+  for (int t = threadIdx.x; t < a.nd; t += blockDim.x)
+    displ[t] = a.disp[t];
+
+  const int p = blockIdx.x % a.nMaps;
+  const int ocg = blockIdx.x / a.nMaps;
+  const int oc_raw = ocg * 4 + wave;
+  const bool oc_valid = oc_raw < a.nOC;
+  const int oc = oc_valid ? oc_raw : a.nOC - 1;
+  const size_t M = (size_t) N * H;
+  const float4 *F4 = reinterpret_cast<const float4 *>(a.ref + (size_t) p * M);
+  const float4 *C4 = reinterpret_cast<const float4 *>(a.conv + (size_t) oc * M);
+
+  const int nhalf = (Hs + 63) / 64;
+  for (int half = 0; half < nhalf; half++)
+  {
+    const int ky = half * 64 + lane;
+    const int kyc = ky < H ? ky : H - 1;
+    float Tr[NW], Ti[NW];
+#pragma unroll
+    for (int d = 0; d < NW; d++)
+    {
+      Tr[d] = 0.f;
+      Ti[d] = 0.f;
+    }
+    for (int k1 = 0; k1 < N1; k1++)
+    {
+      float xr[32], xi[32];
+      const size_t base = (size_t) (k1 * 16) * H + kyc;
+#pragma unroll
+      for (int k2p = 0; k2p < 16; k2p++)
+      {
+        const float4 f = F4[base + (size_t) k2p * H];
+        const float4 c = C4[base + (size_t) k2p * H];
+        // X = conv * conj(ref)   (bioem.cpp:1452-1455)
+        xr[2 * k2p] = fmaf(c.x, f.x, c.y * f.y);
+        xi[2 * k2p] = fmaf(c.y, f.x, -(c.x * f.y));
+        xr[2 * k2p + 1] = fmaf(c.z, f.z, c.w * f.w);
+        xi[2 * k2p + 1] = fmaf(c.w, f.z, -(c.z * f.w));
+      }
+      fft32_inverse(xr, xi);
+      // recombination of the N1 sub-transforms for the displacement window only:
+      //   T[dx] += w_N^(dx*k1) * y_k1[dx mod 32]
+#pragma unroll
+      for (int d = -WD; d <= WD; d++)
+      {
+        const int pos = bitrev5(d & 31);
+        const int tix = d >= 0 ? d * k1 : N + d * k1; // uniform; table has N+1 entries
+        const float2 w = a.tw[tix];
+        float tr = Tr[d + WD], ti = Ti[d + WD];
+        tr = fmaf(xr[pos], w.x, tr);
+        tr = fmaf(-xi[pos], w.y, tr);
+        ti = fmaf(xr[pos], w.y, ti);
+        ti = fmaf(xi[pos], w.x, ti);
+        Tr[d + WD] = tr;
+        Ti[d + WD] = ti;
+      }
+    }
+    // FFTW c2r convention: columns 0 and N/2 enter once (real part only after the ky pass), others twice
+    float wgt = 2.f;
+    if (ky == 0 || (((N & 1) == 0) && ky == N / 2))
+      wgt = 1.f;
+    if (ky >= H)
+      wgt = 0.f;
+    if (ky < Hs)
+    {
+#pragma unroll
+      for (int d = 0; d < NW; d++)
+        Tl[d * Hs + ky] = make_float2(Tr[d] * wgt, Ti[d] * wgt);
+    }
+  }
+  __syncthreads();
+
+  const bioem_hip_param5 q = a.params[oc];
+  Lse L;
+  lse_init(L);
+  window_eval<WD, NR>(a, Tl, Hs, twl, displ, q, a.sumRef[p], a.sumsqRef[p], L);
+  lse_wave_reduce(L);
+  if (lane == 0 && oc_valid)
+  {
+    Partial r;
+    r.sumExp = L.s;
+    r.best = L.m;
+    r.id = L.id;
+    r.value = L.val;
+    r.pad = 0;
+    a.partials[(size_t) p * a.ldPart + oc] = r;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// generic comparison kernel: any N, any maxD.  Reference layout.  One wave per comparison;
+// T[dx][ky] = sum_kx X[kx][ky] w^(kx dx) by direct summation.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_compare_generic(const CompareArgs a)
+{
+  extern __shared__ __align__(16) unsigned char smem[];
+  const int N = a.N, H = a.H;
+  const int Hs = (H + 1) & ~1;
+  const int NW = 2 * a.maxD + 1;
+  float2 *twl = reinterpret_cast<float2 *>(smem);
+  int *displ = reinterpret_cast<int *>(smem + (size_t) ((N + 2) & ~1) * 8);
+  float2 *Tall = reinterpret_cast<float2 *>(smem + (size_t) ((N + 2) & ~1) * 8 + 256);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  float2 *Tl = Tall + (size_t) wave * NW * Hs;
+  for (int t = threadIdx.x; t <= N; t += blockDim.x)
+    twl[t] = a.tw[t];
+  for (int t = threadIdx.x; t < a.nd; t += blockDim.x)
+    displ[t] = a.disp[t];
+  __syncthreads();
+
+  const int p = blockIdx.x % a.nMaps;
+  const int ocg = blockIdx.x / a.nMaps;
+  const int oc_raw = ocg * 4 + wave;
+  const bool oc_valid = oc_raw < a.nOC;
+  const int oc = oc_valid ? oc_raw : a.nOC - 1;
+  const size_t M = (size_t) N * H;
+  const float2 *F = a.ref + (size_t) p * M;
+  const float2 *C = a.conv + (size_t) oc * M;
+
+  for (int e = lane; e < NW * Hs; e += 64)
+  {
+    const int dxi = e / Hs, ky = e - dxi * Hs;
+    float tr = 0.f, ti = 0.f;
+    if (ky < H)
+    {
+      const int dx = dxi - a.maxD;
+      const int step = dx < 0 ? dx + N : dx;
+      int idx = 0;
+      for (int kx = 0; kx < N; kx++)
+      {
+        const float2 c = C[(size_t) kx * H + ky], f = F[(size_t) kx * H + ky];
+        const float xr = fmaf(c.x, f.x, c.y * f.y);
+        const float xi = fmaf(c.y, f.x, -(c.x * f.y));
+        const float2 w = twl[idx];
+        tr = fmaf(xr, w.x, tr);
+        tr = fmaf(-xi, w.y, tr);
+        ti = fmaf(xr, w.y, ti);
+        ti = fmaf(xi, w.x, ti);
+        idx += step;
+        if (idx >= N)
+          idx -= N;
+      }
+      float wgt = 2.f;
+      if (ky == 0 || (((N & 1) == 0) && ky == N / 2))
+        wgt = 1.f;
+      tr *= wgt;
+      ti *= wgt;
+    }
+    Tl[dxi * Hs + ky] = make_float2(tr, ti);
+  }
+  __syncthreads();
+
+  const bioem_hip_param5 q = a.params[oc];
+  double t2, prior;
+  logpro_consts(a.pd, q, t2, prior);
+  const float sumref = a.sumRef[p], sumsqref = a.sumsqRef[p];
+  const float nn = (float) (N * N);
+  Lse L;
+  lse_init(L);
+  const int nd = a.nd;
+  for (int e = lane; e < nd * nd; e += 64)
+  {
+    const int ix = e / nd, iy = e - ix * nd;
+    const int dy = displ[iy];
+    const int step = dy < 0 ? dy + N : dy;
+    const float2 *row = Tl + (size_t) (displ[ix] + a.maxD) * Hs;
+    float acc = 0.f;
+    int idx = 0;
+    for (int ky = 0; ky < H; ky++)
+    {
+      const float2 t = row[ky], w = twl[idx];
+      acc = fmaf(t.x, w.x, acc);
+      acc = fmaf(-t.y, w.y, acc);
+      idx += step;
+      if (idx >= N)
+        idx -= N;
+    }
+    const float value = acc / nn;
+    const double lp = logpro_eval(a.pd, q, value, sumref, sumsqref, t2, prior);
+    lse_push(L, lp, e, value, a.algo);
+  }
+  lse_wave_reduce(L);
+  if (lane == 0 && oc_valid)
+  {
+    Partial r;
+    r.sumExp = L.s;
+    r.best = L.m;
+    r.id = L.id;
+    r.value = L.val;
+    r.pad = 0;
+    a.partials[(size_t) p * a.ldPart + oc] = r;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// fold: one thread per particle walks its partials in (orientation, CTF) order.
+// bioem_algorithm.h:94-141 / bioem.cpp:1527-1600.
+// ------------------------------------------------------------------------------------------------
+__global__ void k_fold(const Partial *__restrict__ partials, int ldPart, int nOC, int nMaps,
+                       const bioem_hip_param5 *__restrict__ params, const float *__restrict__ sumRef,
+                       const int *__restrict__ disp, int nd, PD pd, int orient0, int conv0, int convPerOrient,
+                       bioem_hip_prob_map *__restrict__ pmap, bioem_hip_prob_angle *__restrict__ pang)
+{
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= nMaps)
+    return;
+  bioem_hip_prob_map pm = pmap[p];
+  const float sumref = sumRef[p];
+  const Partial *P = partials + (size_t) p * ldPart;
+  for (int oc = 0; oc < nOC; oc++)
+  {
+    const Partial r = P[oc];
+    const int iOrient = orient0 + oc / convPerOrient;
+    const int iConv = conv0 + oc % convPerOrient;
+    const double lp = (double) r.best;
+    if (pm.Constoadd < lp)
+    {
+      pm.Total *= exp(-lp + pm.Constoadd);
+      pm.Constoadd = lp;
+      const int ix = r.id / nd, iy = r.id - ix * nd;
+      pm.max_prob_cent_x = -disp[ix];
+      pm.max_prob_cent_y = -disp[iy];
+      pm.max_prob_orient = iOrient;
+      pm.max_prob_conv = iConv;
+      const bioem_hip_param5 q = params[oc];
+      const float value = r.value;
+      pm.max_prob_norm = -(-q.sumC * sumref + pd.Ntotpi * value) / (q.sumC * q.sumC - q.sumsquareC * pd.Ntotpi);
+      pm.max_prob_mu = -(-q.sumC * value + q.sumsquareC * sumref) / (q.sumC * q.sumC - q.sumsquareC * pd.Ntotpi);
+    }
+    pm.Total += r.sumExp * exp(lp - pm.Constoadd);
+    if (pd.writeAngles)
+    {
+      bioem_hip_prob_angle pa = pang[(size_t) iOrient * nMaps + p];
+      if (pa.ConstAngle < lp)
+      {
+        pa.forAngles *= exp(-lp + pa.ConstAngle);
+        pa.ConstAngle = lp;
+      }
+      pa.forAngles += r.sumExp * exp(lp - pa.ConstAngle);
+      pang[(size_t) iOrient * nMaps + p] = pa;
+    }
+  }
+  pmap[p] = pm;
+}
+
+// ------------------------------------------------------------------------------------------------
+// host helpers
+// ------------------------------------------------------------------------------------------------
+size_t compare_lds_bytes(int N, int H, int NW, int waves)
+{
+  const int Hs = (H + 1) & ~1;
+  return (size_t) ((N + 2) & ~1) * 8 + 256 + (size_t) waves * NW * Hs * 8;
+}
+
+hipEvent_t get_event(bioem_hip_ctx *h)
+{
+  if (!h->evPool.empty())
+  {
+    hipEvent_t e = h->evPool.back();
+    h->evPool.pop_back();
+    return e;
+  }
+  hipEvent_t e;
+  if (hipEventCreate(&e) != hipSuccess)
+    return nullptr;
+  return e;
+}
+
+void drain_events(bioem_hip_ctx *h)
+{
+  for (auto &pr : h->evPending)
+  {
+    float ms = 0.f;
+    if (hipEventSynchronize(pr.second) == hipSuccess && hipEventElapsedTime(&ms, pr.first, pr.second) == hipSuccess)
+      h->compareMs += (double) ms;
+    h->evPool.push_back(pr.first);
+    h->evPool.push_back(pr.second);
+  }
+  h->evPending.clear();
+}
+
+int launch_compare_fold(bioem_hip_ctx *h, int nOC, int orient0, int conv0, int convPerOrient)
+{
+  CompareArgs a;
+  a.ref = h->dRef;
+  a.conv = h->dConv;
+  a.params = h->dParams;
+  a.sumRef = h->dSumRef;
+  a.sumsqRef = h->dSumsqRef;
+  a.tw = h->dTw;
+  a.disp = h->dDisp;
+  a.partials = h->dPartials;
+  a.ldPart = h->maxOC;
+  a.N = h->N;
+  a.H = h->H;
+  a.N1 = h->N1;
+  a.nd = h->nd;
+  a.maxD = h->pd.maxDisplaceCenter;
+  a.nOC = nOC;
+  a.nMaps = h->nMaps;
+  a.algo = h->algo;
+  a.pd = h->pd;
+  const int ocGroups = (nOC + 3) / 4;
+  const dim3 grid((unsigned) ((size_t) ocGroups * h->nMaps));
+  hipEvent_t e0 = get_event(h), e1 = get_event(h);
+  if (!e0 || !e1)
+  {
+    h->err = "hipEventCreate failed";
+    return 1;
+  }
+  HIP_CHECK(h, hipEventRecord(e0, h->stream));
+  if (h->fast)
+  {
+    const int NW = 2 * h->winD + 1;
+    const size_t lds = compare_lds_bytes(h->N, h->H, NW, 4);
+    if (h->winD == 10)
+      hipLaunchKernelGGL(k_compare_fast<10>, grid, dim3(256), lds, h->stream, a);
+    else
+      hipLaunchKernelGGL(k_compare_fast<15>, grid, dim3(256), lds, h->stream, a);
+  }
+  else
+  {
+    const size_t lds = compare_lds_bytes(h->N, h->H, 2 * h->pd.maxDisplaceCenter + 1, 4);
+    hipLaunchKernelGGL(k_compare_generic, grid, dim3(256), lds, h->stream, a);
+  }
+  HIP_CHECK(h, hipGetLastError());
+  HIP_CHECK(h, hipEventRecord(e1, h->stream));
+  h->evPending.push_back({e0, e1});
+  h->launches++;
+  h->comparisons += (long long) nOC * h->nMaps;
+  bioem_hip_prob_map *pmap = reinterpret_cast<bioem_hip_prob_map *>(h->dProb);
+  bioem_hip_prob_angle *pang = reinterpret_cast<bioem_hip_prob_angle *>(h->dProb + sizeof(bioem_hip_prob_map) * h->nMaps);
+  hipLaunchKernelGGL(k_fold, dim3((h->nMaps + 127) / 128), dim3(128), 0, h->stream, h->dPartials, h->maxOC, nOC,
+                     h->nMaps, h->dParams, h->dSumRef, h->dDisp, h->nd, h->pd, orient0, conv0, convPerOrient, pmap,
+                     pang);
+  HIP_CHECK(h, hipGetLastError());
+  if (h->evPending.size() > 512)
+    drain_events(h);
+  return 0;
+}
+
+// r2c of nImg images (either double projection maps with tempden scaling, or float maps) into dSpecRef
+int run_r2c(bioem_hip_ctx *h, const double *srcD, const float *srcF, int nImg)
+{
+  const int N = h->N, H = h->H;
+  hipLaunchKernelGGL(k_dft_rows, dim3(N, nImg), dim3(128), sizeof(double) * N, h->stream, srcD, srcF, h->dTempDen,
+                     h->NormDen, N, H, h->dTwD, h->dRowSpec);
+  HIP_CHECK(h, hipGetLastError());
+  hipLaunchKernelGGL(k_dft_cols, dim3(H, nImg), dim3(256), sizeof(double2) * N, h->stream, h->dRowSpec, N, H, h->dTwD,
+                     h->dSpecRef);
+  HIP_CHECK(h, hipGetLastError());
+  return 0;
+}
+
+int project_batch(bioem_hip_ctx *h, int o0, int nO)
+{
+  const int N = h->N;
+  HIP_CHECK(h, hipMemsetAsync(h->dProjReal, 0, sizeof(double) * (size_t) nO * N * N, h->stream));
+  HIP_CHECK(h, hipMemsetAsync(h->dTempDen, 0, sizeof(double) * nO, h->stream));
+  hipLaunchKernelGGL(k_project, dim3((h->nPts + 255) / 256, nO), dim3(256), 0, h->stream, h->dPts, h->nPts,
+                     h->dAngles, o0, h->isQuat, N, h->pixelSize, h->shiftX, h->shiftY, h->dProjReal, h->dTempDen);
+  HIP_CHECK(h, hipGetLastError());
+  return run_r2c(h, h->dProjReal, nullptr, nO);
+}
+
+int convolve_batch(bioem_hip_ctx *h, int nO)
+{
+  hipLaunchKernelGGL(k_convolve, dim3(h->nCTF, nO), dim3(256), 0, h->stream, h->dSpecRef, h->dCTF, h->dCtfParam, h->N,
+                     h->H, h->fast, h->N1, h->nCTF, h->dConv, h->dScratch, h->dParams);
+  HIP_CHECK(h, hipGetLastError());
+  return 0;
+}
+
+} // namespace
+
+// ================================================================================================
+// C ABI
+// ================================================================================================
+extern "C" {
+
+int bioem_hip_device_count(void)
+{
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess)
+    return 0;
+  return n;
+}
+
+size_t bioem_hip_prob_size(int nMaps, int nAngles, int writeAngles)
+{
+  size_t size = sizeof(bioem_hip_prob_map);
+  if (writeAngles)
+    size += (size_t) nAngles * sizeof(bioem_hip_prob_angle);
+  return (size_t) nMaps * size;
+}
+
+const char *bioem_hip_last_error(bioem_hip_handle h) { return h ? h->err.c_str() : "null handle"; }
+
+int bioem_hip_create(bioem_hip_handle *out, int device, const bioem_hip_param_device *pd, int nMaps, int nAngles,
+                     int nCTF, int algo)
+{
+  if (!out || !pd)
+    return 2;
+  bioem_hip_ctx *h = new bioem_hip_ctx;
+  *out = h;
+  h->device = device;
+  h->pd = *pd;
+  h->nMaps = nMaps;
+  h->nAngles = nAngles;
+  h->nCTF = nCTF;
+  h->algo = algo;
+  const int N = pd->NumberPixels;
+  h->N = N;
+  h->H = N / 2 + 1;
+  h->M = N * h->H;
+  if (N < 2 || nMaps < 1 || nAngles < 1 || nCTF < 1 || pd->maxDisplaceCenter < 0 || pd->GridSpaceCenter < 1 ||
+      pd->maxDisplaceCenter >= N / 2)
+  {
+    h->err = "invalid configuration (need N>=2, nMaps,nAngles,nCTF>=1, 0<=maxD<N/2, grid>=1)";
+    return 2;
+  }
+  HIP_CHECK(h, hipSetDevice(device));
+  HIP_CHECK(h, hipStreamCreate(&h->stream));
+
+  // displacement list per axis in the reference's visiting order
+  const int maxD = pd->maxDisplaceCenter, g = pd->GridSpaceCenter;
+  if (algo == 1)
+  { // bioem_algorithm.h:156-197
+    for (int c = 0; c <= maxD; c += g)
+      h->disp.push_back(c);
+    for (int c = N - maxD; c < N; c += g)
+      h->disp.push_back(c - N);
+  }
+  else
+  { // bioem.cpp:1477-1485
+    const int NxDisp = 2 * (maxD / g) + 1;
+    for (int m = 0; m < NxDisp; m++)
+      h->disp.push_back(m * g - maxD);
+  }
+  h->nd = (int) h->disp.size();
+
+  h->fast = (N % 32 == 0 && maxD <= 15 && h->nd <= 31) ? 1 : 0;
+  h->N1 = h->fast ? N / 32 : 0;
+  h->winD = maxD <= 10 ? 10 : 15;
+  if (h->fast && h->winD == 10 && h->nd > 21)
+    h->winD = 15;
+  // LDS budget check
+  {
+    const int NW = h->fast ? 2 * h->winD + 1 : 2 * maxD + 1;
+    const size_t lds = compare_lds_bytes(N, h->H, NW, 4);
+    if (lds > 160 * 1024)
+    {
+      if (h->fast && compare_lds_bytes(N, h->H, 2 * maxD + 1, 4) <= 160 * 1024)
+        h->fast = 0;
+      else
+      {
+        h->err = "configuration exceeds the 160 KiB LDS budget of the comparison kernel";
+        return 2;
+      }
+    }
+    if (h->fast)
+    {
+      if (h->winD == 10)
+        HIP_CHECK(h, hipFuncSetAttribute(reinterpret_cast<const void *>(k_compare_fast<10>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
+      else
+        HIP_CHECK(h, hipFuncSetAttribute(reinterpret_cast<const void *>(k_compare_fast<15>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
+    }
+    else
+    {
+      const size_t ldsg = compare_lds_bytes(N, h->H, 2 * maxD + 1, 4);
+      HIP_CHECK(h, hipFuncSetAttribute(reinterpret_cast<const void *>(k_compare_generic),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int) ldsg));
+    }
+  }
+
+  // batch sizing: conv buffer <= ~96 MiB, partial buffer <= ~128 MiB
+  const size_t M = (size_t) h->M;
+  size_t ocCap = (96u << 20) / (M * sizeof(float2));
+  const size_t partCap = (128u << 20) / ((size_t) nMaps * sizeof(Partial));
+  if (ocCap > partCap)
+    ocCap = partCap;
+  int OB = (int) (ocCap / (size_t) nCTF);
+  if (OB < 1)
+    OB = 1;
+  if (OB > 64)
+    OB = 64;
+  if (OB > nAngles)
+    OB = nAngles;
+  h->OB = OB;
+  h->maxOC = OB * nCTF;
+  h->chunkB = OB > 32 ? OB : 32;
+
+  HIP_CHECK(h, hipMalloc(&h->dRef, sizeof(float2) * M * nMaps));
+  HIP_CHECK(h, hipMalloc(&h->dSumRef, sizeof(float) * nMaps));
+  HIP_CHECK(h, hipMalloc(&h->dSumsqRef, sizeof(float) * nMaps));
+  HIP_CHECK(h, hipMalloc(&h->dCTF, sizeof(float2) * M * nCTF));
+  HIP_CHECK(h, hipMalloc(&h->dCtfParam, sizeof(float) * 3 * nCTF));
+  HIP_CHECK(h, hipMalloc(&h->dAngles, sizeof(float4) * nAngles));
+  HIP_CHECK(h, hipMalloc(&h->dTw, sizeof(float2) * (N + 1)));
+  HIP_CHECK(h, hipMalloc(&h->dTwD, sizeof(double2) * N));
+  HIP_CHECK(h, hipMalloc(&h->dDisp, sizeof(int) * h->nd));
+  HIP_CHECK(h, hipMalloc(&h->dProjReal, sizeof(double) * (size_t) h->chunkB * N * N));
+  HIP_CHECK(h, hipMalloc(&h->dTempDen, sizeof(double) * h->chunkB));
+  HIP_CHECK(h, hipMalloc(&h->dRowSpec, sizeof(double2) * (size_t) h->chunkB * M));
+  HIP_CHECK(h, hipMalloc(&h->dSpecRef, sizeof(float2) * (size_t) h->chunkB * M));
+  HIP_CHECK(h, hipMalloc(&h->dScratch, sizeof(float) * (size_t) h->maxOC * M));
+  HIP_CHECK(h, hipMalloc(&h->dConv, sizeof(float2) * (size_t) h->maxOC * M));
+  HIP_CHECK(h, hipMalloc(&h->dParams, sizeof(bioem_hip_param5) * h->maxOC));
+  HIP_CHECK(h, hipMalloc(&h->dPartials, sizeof(Partial) * (size_t) nMaps * h->maxOC));
+  h->probBytes = bioem_hip_prob_size(nMaps, nAngles, pd->writeAngles);
+  HIP_CHECK(h, hipMalloc(&h->dProb, h->probBytes));
+
+  std::vector<float2> tw(N + 1);
+  std::vector<double2> twd(N);
+  for (int k = 0; k <= N; k++)
+  {
+    const double ang = 2.0 * M_PI * (double) (k % N) / (double) N;
+    tw[k] = make_float2((float) cos(ang), (float) sin(ang));
+    if (k < N)
+      twd[k] = make_double2(cos(ang), sin(ang));
+  }
+  HIP_CHECK(h, hipMemcpy(h->dTw, tw.data(), sizeof(float2) * (N + 1), hipMemcpyHostToDevice));
+  HIP_CHECK(h, hipMemcpy(h->dTwD, twd.data(), sizeof(double2) * N, hipMemcpyHostToDevice));
+  HIP_CHECK(h, hipMemcpy(h->dDisp, h->disp.data(), sizeof(int) * h->nd, hipMemcpyHostToDevice));
+  HIP_CHECK(h, hipEventCreateWithFlags(&h->slotEvent[0], hipEventDisableTiming));
+  HIP_CHECK(h, hipEventCreateWithFlags(&h->slotEvent[1], hipEventDisableTiming));
+  return 0;
+}
+
+int bioem_hip_destroy(bioem_hip_handle h)
+{
+  if (!h)
+    return 0;
+  hipSetDevice(h->device);
+  if (h->stream)
+    hipStreamSynchronize(h->stream);
+  drain_events(h);
+  for (hipEvent_t e : h->evPool)
+    hipEventDestroy(e);
+  void *ptrs[] = {h->dRef,     h->dSumRef,  h->dSumsqRef, h->dCTF,     h->dCtfParam, h->dPts,   h->dAngles,
+                  h->dTw,      h->dTwD,     h->dDisp,     h->dProjReal, h->dTempDen,  h->dRowSpec, h->dSpecRef,
+                  h->dScratch, h->dConv,    h->dParams,   h->dPartials, h->dProb,     h->dStage};
+  for (void *p : ptrs)
+    if (p)
+      hipFree(p);
+  if (h->hStage)
+    hipHostFree(h->hStage);
+  if (h->hStageP)
+    hipHostFree(h->hStageP);
+  for (int i = 0; i < 2; i++)
+    if (h->slotEvent[i])
+      hipEventDestroy(h->slotEvent[i]);
+  if (h->stream)
+    hipStreamDestroy(h->stream);
+  delete h;
+  return 0;
+}
+
+int bioem_hip_upload_particles(bioem_hip_handle h, const float *refFFT, const float *sum, const float *sumsq)
+{
+  HIP_CHECK(h, hipSetDevice(h->device));
+  const size_t M = (size_t) h->M;
+  HIP_CHECK(h, hipMemcpyAsync(h->dSumRef, sum, sizeof(float) * h->nMaps, hipMemcpyHostToDevice, h->stream));
+  HIP_CHECK(h, hipMemcpyAsync(h->dSumsqRef, sumsq, sizeof(float) * h->nMaps, hipMemcpyHostToDevice, h->stream));
+  for (int b = 0; b < h->nMaps; b += h->chunkB)
+  {
+    const int n = std::min(h->chunkB, h->nMaps - b);
+    HIP_CHECK(h, hipMemcpyAsync(h->dSpecRef, refFFT + 2 * M * (size_t) b, sizeof(float2) * M * n,
+                                hipMemcpyHostToDevice, h->stream));
+    hipLaunchKernelGGL(k_reorder, dim3(1024), dim3(256), 0, h->stream, h->dSpecRef, h->dRef + M * (size_t) b, n, h->N,
+                       h->H, h->fast, h->N1);
+    HIP_CHECK(h, hipGetLastError());
+    HIP_CHECK(h, hipStreamSynchronize(h->stream));
+  }
+  return 0;
+}
+
+int bioem_hip_upload_particle_maps(bioem_hip_handle h, const float *maps)
+{
+  HIP_CHECK(h, hipSetDevice(h->device));
+  const size_t M = (size_t) h->M;
+  const int N = h->N;
+  float *dMaps = nullptr;
+  HIP_CHECK(h, hipMalloc(&dMaps, sizeof(float) * (size_t) h->chunkB * N * N));
+  for (int b = 0; b < h->nMaps; b += h->chunkB)
+  {
+    const int n = std::min(h->chunkB, h->nMaps - b);
+    HIP_CHECK(h, hipMemcpyAsync(dMaps, maps + (size_t) b * N * N, sizeof(float) * (size_t) n * N * N,
+                                hipMemcpyHostToDevice, h->stream));
+    hipLaunchKernelGGL(k_map_sums, dim3(n), dim3(256), 0, h->stream, dMaps, N * N, h->dSumRef + b, h->dSumsqRef + b);
+    HIP_CHECK(h, hipGetLastError());
+    if (run_r2c(h, nullptr, dMaps, n))
+    {
+      hipFree(dMaps);
+      return 1;
+    }
+    hipLaunchKernelGGL(k_reorder, dim3(1024), dim3(256), 0, h->stream, h->dSpecRef, h->dRef + M * (size_t) b, n, N,
+                       h->H, h->fast, h->N1);
+    HIP_CHECK(h, hipGetLastError());
+    HIP_CHECK(h, hipStreamSynchronize(h->stream));
+  }
+  hipFree(dMaps);
+  return 0;
+}
+
+int bioem_hip_upload_ctf(bioem_hip_handle h, const float *refCTF, const float *ctfParam3)
+{
+  HIP_CHECK(h, hipSetDevice(h->device));
+  HIP_CHECK(h, hipMemcpy(h->dCTF, refCTF, sizeof(float2) * (size_t) h->M * h->nCTF, hipMemcpyHostToDevice));
+  HIP_CHECK(h, hipMemcpy(h->dCtfParam, ctfParam3, sizeof(float) * 3 * h->nCTF, hipMemcpyHostToDevice));
+  return 0;
+}
+
+int bioem_hip_upload_model(bioem_hip_handle h, const bioem_hip_model_point *pts, int nPts, float NormDen,
+                           float pixelSize, int shiftX, int shiftY)
+{
+  HIP_CHECK(h, hipSetDevice(h->device));
+  if (h->dPts)
+    hipFree(h->dPts);
+  h->dPts = nullptr;
+  HIP_CHECK(h, hipMalloc(&h->dPts, sizeof(bioem_hip_model_point) * (size_t) nPts));
+  HIP_CHECK(h, hipMemcpy(h->dPts, pts, sizeof(bioem_hip_model_point) * (size_t) nPts, hipMemcpyHostToDevice));
+  h->nPts = nPts;
+  h->NormDen = NormDen;
+  h->pixelSize = pixelSize;
+  h->shiftX = shiftX;
+  h->shiftY = shiftY;
+  return 0;
+}
+
+int bioem_hip_upload_orientations(bioem_hip_handle h, const float *angles4, int n, int isQuat)
+{
+  HIP_CHECK(h, hipSetDevice(h->device));
+  if (n > h->nAngles)
+  {
+    h->err = "more orientations than the handle was created for";
+    return 2;
+  }
+  HIP_CHECK(h, hipMemcpy(h->dAngles, angles4, sizeof(float4) * (size_t) n, hipMemcpyHostToDevice));
+  h->nAnglesUp = n;
+  h->isQuat = isQuat;
+  return 0;
+}
+
+void *bioem_hip_host_alloc(size_t size)
+{
+  void *p = nullptr;
+  if (hipHostMalloc(&p, size, hipHostMallocDefault) != hipSuccess)
+    return nullptr;
+  return p;
+}
+
+void bioem_hip_host_free(void *ptr)
+{
+  if (ptr)
+    hipHostFree(ptr);
+}
+
+int bioem_hip_start_run(bioem_hip_handle h, const void *pProb_host)
+{
+  HIP_CHECK(h, hipSetDevice(h->device));
+  HIP_CHECK(h, hipMemcpyAsync(h->dProb, pProb_host, h->probBytes, hipMemcpyHostToDevice, h->stream));
+  HIP_CHECK(h, hipStreamSynchronize(h->stream));
+  return 0;
+}
+
+int bioem_hip_compare(bioem_hip_handle h, int iPipeline, int iOrient, int iConvStart, int maxParallelConv,
+                      int nTotParallelConv, const float *conv_mapsFFT, const bioem_hip_param5 *comp_params)
+{
+  HIP_CHECK(h, hipSetDevice(h->device));
+  const size_t M = (size_t) h->M;
+  if (maxParallelConv < 1 || maxParallelConv > nTotParallelConv || maxParallelConv > h->maxOC)
+  {
+    h->err = "bioem_hip_compare: maxParallelConv out of range";
+    return 2;
+  }
+  if (h->stageConv < nTotParallelConv)
+  {
+    HIP_CHECK(h, hipStreamSynchronize(h->stream));
+    if (h->hStage)
+      hipHostFree(h->hStage);
+    if (h->hStageP)
+      hipHostFree(h->hStageP);
+    if (h->dStage)
+      hipFree(h->dStage);
+    HIP_CHECK(h, hipHostMalloc(&h->hStage, sizeof(float2) * M * 2 * nTotParallelConv, hipHostMallocDefault));
+    HIP_CHECK(h, hipHostMalloc(&h->hStageP, sizeof(bioem_hip_param5) * 2 * nTotParallelConv, hipHostMallocDefault));
+    HIP_CHECK(h, hipMalloc(&h->dStage, sizeof(float2) * M * nTotParallelConv));
+    h->stageConv = nTotParallelConv;
+  }
+  const int par = iPipeline & 1;
+  const int k = par * nTotParallelConv; // bioem.cpp:1388
+  if (h->slotPending[par])
+  {
+    HIP_CHECK(h, hipEventSynchronize(h->slotEvent[par])); // bioem_cuda.cu:539
+    h->slotPending[par] = false;
+  }
+  memcpy(h->hStage + M * k, conv_mapsFFT + 2 * M * k, sizeof(float2) * M * maxParallelConv);
+  memcpy(h->hStageP + k, comp_params + k, sizeof(bioem_hip_param5) * maxParallelConv);
+  HIP_CHECK(h, hipMemcpyAsync(h->dStage, h->hStage + M * k, sizeof(float2) * M * maxParallelConv,
+                              hipMemcpyHostToDevice, h->stream));
+  HIP_CHECK(h, hipMemcpyAsync(h->dParams, h->hStageP + k, sizeof(bioem_hip_param5) * maxParallelConv,
+                              hipMemcpyHostToDevice, h->stream));
+  hipLaunchKernelGGL(k_reorder, dim3(256), dim3(256), 0, h->stream, h->dStage, h->dConv, maxParallelConv, h->N, h->H,
+                     h->fast, h->N1);
+  HIP_CHECK(h, hipGetLastError());
+  if (launch_compare_fold(h, maxParallelConv, iOrient, iConvStart, maxParallelConv))
+    return 1;
+  HIP_CHECK(h, hipEventRecord(h->slotEvent[par], h->stream));
+  h->slotPending[par] = true;
+  return 0;
+}
+
+int bioem_hip_project_convolve_compare(bioem_hip_handle h, int iOrientBegin, int iOrientEnd)
+{
+  HIP_CHECK(h, hipSetDevice(h->device));
+  if (!h->dPts || iOrientBegin < 0 || iOrientEnd > h->nAnglesUp || iOrientBegin > iOrientEnd)
+  {
+    h->err = "project_convolve_compare: model/orientations not uploaded or range invalid";
+    return 2;
+  }
+  for (int o0 = iOrientBegin; o0 < iOrientEnd; o0 += h->OB)
+  {
+    const int nO = std::min(h->OB, iOrientEnd - o0);
+    if (project_batch(h, o0, nO))
+      return 1;
+    if (convolve_batch(h, nO))
+      return 1;
+    if (launch_compare_fold(h, nO * h->nCTF, o0, 0, h->nCTF))
+      return 1;
+  }
+  return 0;
+}
+
+int bioem_hip_finish_run(bioem_hip_handle h, void *pProb_host)
+{
+  HIP_CHECK(h, hipSetDevice(h->device));
+  HIP_CHECK(h, hipMemcpyAsync(pProb_host, h->dProb, h->probBytes, hipMemcpyDeviceToHost, h->stream));
+  HIP_CHECK(h, hipStreamSynchronize(h->stream));
+  h->slotPending[0] = h->slotPending[1] = false;
+  drain_events(h);
+  return 0;
+}
+
+int bioem_hip_synchronize(bioem_hip_handle h)
+{
+  HIP_CHECK(h, hipSetDevice(h->device));
+  HIP_CHECK(h, hipStreamSynchronize(h->stream));
+  return 0;
+}
+
+int bioem_hip_merge_host(int nShards, int nMaps, int nAngles, int writeAngles, const void *const *shards, void *out)
+{
+  if (nShards < 1)
+    return 2;
+  bioem_hip_prob_map *om = reinterpret_cast<bioem_hip_prob_map *>(out);
+  bioem_hip_prob_angle *oa = reinterpret_cast<bioem_hip_prob_angle *>(om + nMaps);
+  for (int i = 0; i < nMaps; i++)
+  {
+    int who = 0;
+    double cmax = reinterpret_cast<const bioem_hip_prob_map *>(shards[0])[i].Constoadd;
+    for (int s = 1; s < nShards; s++)
+    {
+      const double c = reinterpret_cast<const bioem_hip_prob_map *>(shards[s])[i].Constoadd;
+      if (c > cmax)
+      {
+        cmax = c;
+        who = s;
+      }
+    }
+    double tot = 0.;
+    for (int s = 0; s < nShards; s++)
+    {
+      const bioem_hip_prob_map &m = reinterpret_cast<const bioem_hip_prob_map *>(shards[s])[i];
+      tot += m.Total * exp(m.Constoadd - cmax);
+    }
+    om[i] = reinterpret_cast<const bioem_hip_prob_map *>(shards[who])[i];
+    om[i].Total = tot;
+    om[i].Constoadd = cmax;
+  }
+  if (writeAngles)
+  {
+    const size_t cnt = (size_t) nMaps * nAngles;
+    for (size_t e = 0; e < cnt; e++)
+    {
+      double cmax = MIN_PROB;
+      for (int s = 0; s < nShards; s++)
+      {
+        const bioem_hip_prob_angle *a =
+            reinterpret_cast<const bioem_hip_prob_angle *>(reinterpret_cast<const bioem_hip_prob_map *>(shards[s]) + nMaps);
+        if (a[e].ConstAngle > cmax)
+          cmax = a[e].ConstAngle;
+      }
+      double tot = 0.;
+      for (int s = 0; s < nShards; s++)
+      {
+        const bioem_hip_prob_angle *a =
+            reinterpret_cast<const bioem_hip_prob_angle *>(reinterpret_cast<const bioem_hip_prob_map *>(shards[s]) + nMaps);
+        tot += a[e].forAngles * exp(a[e].ConstAngle - cmax);
+      }
+      oa[e].forAngles = tot;
+      oa[e].ConstAngle = cmax;
+    }
+  }
+  return 0;
+}
+
+int bioem_hip_debug_projection(bioem_hip_handle h, int iOrient, float *spec_out)
+{
+  HIP_CHECK(h, hipSetDevice(h->device));
+  if (project_batch(h, iOrient, 1))
+    return 1;
+  HIP_CHECK(h, hipMemcpyAsync(spec_out, h->dSpecRef, sizeof(float2) * (size_t) h->M, hipMemcpyDeviceToHost, h->stream));
+  HIP_CHECK(h, hipStreamSynchronize(h->stream));
+  return 0;
+}
+
+int bioem_hip_debug_convolution(bioem_hip_handle h, int iOrient, int iConv, float *spec_out, float *sumC,
+                                float *sumsquareC)
+{
+  HIP_CHECK(h, hipSetDevice(h->device));
+  if (project_batch(h, iOrient, 1))
+    return 1;
+  if (convolve_batch(h, 1))
+    return 1;
+  const size_t M = (size_t) h->M;
+  float2 *tmp = h->dSpecRef + M; // chunkB >= 32 slots; slot 0 holds the projection spectrum
+  hipLaunchKernelGGL(k_unreorder, dim3(256), dim3(256), 0, h->stream, h->dConv + M * (size_t) iConv, tmp, 1, h->N,
+                     h->H, h->fast, h->N1);
+  HIP_CHECK(h, hipGetLastError());
+  HIP_CHECK(h, hipMemcpyAsync(spec_out, tmp, sizeof(float2) * M, hipMemcpyDeviceToHost, h->stream));
+  bioem_hip_param5 q;
+  HIP_CHECK(h, hipMemcpyAsync(&q, h->dParams + iConv, sizeof(q), hipMemcpyDeviceToHost, h->stream));
+  HIP_CHECK(h, hipStreamSynchronize(h->stream));
+  *sumC = q.sumC;
+  *sumsquareC = q.sumsquareC;
+  return 0;
+}
+
+int bioem_hip_debug_particles(bioem_hip_handle h, float *refFFT_out, float *sum_out, float *sumsq_out)
+{
+  HIP_CHECK(h, hipSetDevice(h->device));
+  const size_t M = (size_t) h->M;
+  for (int b = 0; b < h->nMaps; b += h->chunkB)
+  {
+    const int n = std::min(h->chunkB, h->nMaps - b);
+    hipLaunchKernelGGL(k_unreorder, dim3(1024), dim3(256), 0, h->stream, h->dRef + M * (size_t) b, h->dSpecRef, n, h->N,
+                       h->H, h->fast, h->N1);
+    HIP_CHECK(h, hipGetLastError());
+    HIP_CHECK(h, hipMemcpyAsync(refFFT_out + 2 * M * (size_t) b, h->dSpecRef, sizeof(float2) * M * n,
+                                hipMemcpyDeviceToHost, h->stream));
+    HIP_CHECK(h, hipStreamSynchronize(h->stream));
+  }
+  HIP_CHECK(h, hipMemcpy(sum_out, h->dSumRef, sizeof(float) * h->nMaps, hipMemcpyDeviceToHost));
+  HIP_CHECK(h, hipMemcpy(sumsq_out, h->dSumsqRef, sizeof(float) * h->nMaps, hipMemcpyDeviceToHost));
+  return 0;
+}
+
+int bioem_hip_kernel_stats(bioem_hip_handle h, double *compare_ms, long long *launches, long long *comparisons)
+{
+  HIP_CHECK(h, hipSetDevice(h->device));
+  HIP_CHECK(h, hipStreamSynchronize(h->stream));
+  drain_events(h);
+  if (compare_ms)
+    *compare_ms = h->compareMs;
+  if (launches)
+    *launches = h->launches;
+  if (comparisons)
+    *comparisons = h->comparisons;
+  return 0;
+}
+
+int bioem_hip_reset_kernel_stats(bioem_hip_handle h)
+{
+  HIP_CHECK(h, hipSetDevice(h->device));
+  HIP_CHECK(h, hipStreamSynchronize(h->stream));
+  drain_events(h);
+  h->compareMs = 0;
+  h->launches = 0;
+  h->comparisons = 0;
+  return 0;
+}
+
+int bioem_hip_uses_fast_path(bioem_hip_handle h) { return h ? h->fast : 0; }
+
+} // extern "C"

@@ -1,0 +1,153 @@
+/* bioem_hip.h -- C ABI of the MI355X-native BioEM likelihood engine (libbioem_hip.so).
+ *
+ * This is the drop-in boundary for the reference's accelerator plugin (class bioem_cuda,
+ * /root/reference/include/bioem_cuda_internal.h:28-85, created by bioem_cuda_create(),
+ * /root/reference/include/bioem_cuda.h:20): plain pointers and sizes, no C++/torch types.
+ * Every entry point names the reference interface it replaces.  All functions return 0 on
+ * success and a non-zero code on failure (bioem_hip_last_error() gives the text); the C++
+ * shim (bioem_amd/host) maps non-zero to the reference's print-and-exit (defs.h:18-26).
+ *
+ * Threading: all entry points of one handle are called from one host thread (the reference
+ * calls its plugin from the main thread only, bioem.cpp:853).  One handle drives one GPU.
+ */
+#ifndef BIOEM_HIP_H
+#define BIOEM_HIP_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* == bioem_param_device, /root/reference/include/param.h:26-47 (60 bytes, bool tousepsf widened) */
+typedef struct
+{
+  int maxDisplaceCenter;
+  int GridSpaceCenter;
+  int NumberPixels;
+  int NumberFFTPixels1D;
+  int NxDisp;
+  int NtotDisp;
+  float Ntotpi;
+  float volu;
+  float sigmaPriorbctf;
+  float sigmaPriordefo;
+  float Priordefcent;
+  float sigmaPrioramp;
+  float Priorampcent;
+  int writeAngles;
+  int tousepsf;
+} bioem_hip_param_device;
+
+/* == myparam5_t, /root/reference/include/defs.h:128-135 (20 bytes) */
+typedef struct
+{
+  float amp, pha, env, sumC, sumsquareC;
+} bioem_hip_param5;
+
+/* == bioem_Probability_map, /root/reference/include/map.h:116-128 (40 bytes) */
+typedef struct
+{
+  double Total;
+  double Constoadd;
+  int max_prob_cent_x, max_prob_cent_y, max_prob_orient, max_prob_conv;
+  float max_prob_norm, max_prob_mu;
+} bioem_hip_prob_map;
+
+/* == bioem_Probability_angle, /root/reference/include/map.h:130-135 (16 bytes) */
+typedef struct
+{
+  double forAngles;
+  double ConstAngle;
+} bioem_hip_prob_angle;
+
+/* == bioem_model::bioem_model_point, /root/reference/include/model.h:23-29 (24 bytes) */
+typedef struct
+{
+  float pos[3];
+  float quat4_unused;
+  float radius;
+  float density;
+} bioem_hip_model_point;
+
+typedef struct bioem_hip_ctx *bioem_hip_handle;
+
+/* Number of visible HIP devices (replaces bioem_cuda::selectCudaDevice, bioem_cuda.cu:686-816). */
+int bioem_hip_device_count(void);
+
+/* Replaces bioem_cuda::deviceInit (bioem_cuda.cu:818-951): allocate device state for nMaps particles,
+ * nAngles orientations, nCTF kernels.  algo = BIOEM_ALGO (1 or 2: displacement set + reduction
+ * semantics of bioem_algorithm.h:144-198 / bioem.cpp:1461-1602).  device = HIP ordinal. */
+int bioem_hip_create(bioem_hip_handle *out, int device, const bioem_hip_param_device *pd, int nMaps, int nAngles,
+                     int nCTF, int algo);
+int bioem_hip_destroy(bioem_hip_handle h); /* bioem_cuda::deviceExit, bioem_cuda.cu:1023-1053 */
+const char *bioem_hip_last_error(bioem_hip_handle h);
+
+/* Particle side.  refFFT = bioem_RefMap::RefMapsFFT [nMaps][N][N/2+1] (re,im), sum/sumsq =
+ * sum_RefMap / sumsquare_RefMap (map.h:65-74; uploaded at bioem_cuda.cu:824-846). */
+int bioem_hip_upload_particles(bioem_hip_handle h, const float *refFFT, const float *sum, const float *sumsq);
+/* North-star variant: real-space maps [nMaps][N][N]; sums (bioem.cpp:2087-2107, same float summation
+ * order) and r2c (map.cpp:557-601) run on the device. */
+int bioem_hip_upload_particle_maps(bioem_hip_handle h, const float *maps);
+
+/* bioem_param::refCTF [nCTF][N][N/2+1] (re,im) and CtfParam [nCTF] as {amp, phase, env} triples
+ * (param.h:76-77, filled at param.cpp:1336-1583). */
+int bioem_hip_upload_ctf(bioem_hip_handle h, const float *refCTF, const float *ctfParam3);
+/* bioem_model::points / NormDen and the projection parameters used by bioem::createProjection
+ * (bioem.cpp:1604-1853). */
+int bioem_hip_upload_model(bioem_hip_handle h, const bioem_hip_model_point *pts, int nPts, float NormDen,
+                           float pixelSize, int shiftX, int shiftY);
+/* bioem_param::angles [n] as {pos0,pos1,pos2,quat4} (defs.h:105-110); isQuat = param.doquater. */
+int bioem_hip_upload_orientations(bioem_hip_handle h, const float *angles4, int n, int isQuat);
+
+/* bioem::malloc_device_host / free_device_host (bioem.h:56-57; bioem_cuda.cu:1037-1053): pinned host memory
+ * for the probability block. */
+void *bioem_hip_host_alloc(size_t size);
+void bioem_hip_host_free(void *ptr);
+/* size of the probability block, == bioem_Probability::get_size (map.h:156-162) */
+size_t bioem_hip_prob_size(int nMaps, int nAngles, int writeAngles);
+
+/* bioem_cuda::deviceStartRun (bioem_cuda.cu:953-1011): upload the (initialised) probability block. */
+int bioem_hip_start_run(bioem_hip_handle h, const void *pProb_host);
+
+/* Reference-compatible hot-path entry == bioem::compareRefMaps (bioem.h:52-54; CUDA override
+ * bioem_cuda.cu:527-684).  conv_mapsFFT / comp_params are the BASE pointers of the caller's 2-slot buffers;
+ * slot offset k = (iPipeline & 1) * nTotParallelConv as in bioem.cpp:1388.  Asynchronous like the CUDA
+ * plugin: returns after enqueue; slot k may be overwritten after the next call with the same parity
+ * has returned. */
+int bioem_hip_compare(bioem_hip_handle h, int iPipeline, int iOrient, int iConvStart, int maxParallelConv,
+                      int nTotParallelConv, const float *conv_mapsFFT, const bioem_hip_param5 *comp_params);
+
+/* North-star entry: bioem::createProjection + createConvolutedProjectionMap + compareRefMaps
+ * (the body of the run() loop, bioem.cpp:763-891) for orientations [iOrientBegin, iOrientEnd) and all CTFs,
+ * entirely on the device. */
+int bioem_hip_project_convolve_compare(bioem_hip_handle h, int iOrientBegin, int iOrientEnd);
+
+/* bioem_cuda::deviceFinishRun (bioem_cuda.cu:1013-1021): synchronise, download the probability block. */
+int bioem_hip_finish_run(bioem_hip_handle h, void *pProb_host);
+
+/* Log-sum-exp merge of orientation shards (replaces the MPI merge of bioem.cpp:909-1044) on the host:
+ * shards = nShards probability blocks of identical shape, out = merged block.  Ties on Constoadd go to
+ * the lowest shard (= lowest orientation index, the serial semantics). */
+int bioem_hip_merge_host(int nShards, int nMaps, int nAngles, int writeAngles, const void *const *shards, void *out);
+
+/* ---- instrumentation / test hooks (no reference equivalent) ---- */
+/* projection spectrum of one orientation in reference layout [N][N/2+1][2] */
+int bioem_hip_debug_projection(bioem_hip_handle h, int iOrient, float *spec_out);
+/* conv spectrum + {sumC, sumsquareC} of (iOrient, iConv) in reference layout */
+int bioem_hip_debug_convolution(bioem_hip_handle h, int iOrient, int iConv, float *spec_out, float *sumC,
+                                float *sumsquareC);
+/* download device-side particle precompute (reference layout) */
+int bioem_hip_debug_particles(bioem_hip_handle h, float *refFFT_out, float *sum_out, float *sumsq_out);
+/* accumulated HIP-event time of the comparison kernel on the engine's stream since the last reset:
+ * total ms, launches, comparisons processed */
+int bioem_hip_kernel_stats(bioem_hip_handle h, double *compare_ms, long long *launches, long long *comparisons);
+int bioem_hip_reset_kernel_stats(bioem_hip_handle h);
+/* 1 if the LDS-FFT fast path is used for this configuration, 0 for the generic pruned-DFT path */
+int bioem_hip_uses_fast_path(bioem_hip_handle h);
+int bioem_hip_synchronize(bioem_hip_handle h);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -870,3 +870,16 @@ double orc_final_logp(const orc_param_device *pd, double Total, double Constoadd
 }
 
 int orc_sizeof_prob_map(void) { return (int) sizeof(orc_prob_map); }
+
+/* thread count of the OpenMP regions (callers pass the CPUs they may actually use) */
+void orc_set_num_threads(int n)
+{
+#ifdef _OPENMP
+  if (n > 0)
+    omp_set_num_threads(n);
+#else
+  (void) n;
+#endif
+}
+
+int orc_get_max_threads(void) { return omp_get_max_threads(); }

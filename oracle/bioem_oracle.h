@@ -128,6 +128,8 @@ void orc_merge(int nShards, int nMaps, const orc_prob_map *shards /* [nShards][n
 double orc_final_logp(const orc_param_device *pd, double Total, double Constoadd);
 
 int orc_sizeof_prob_map(void);
+void orc_set_num_threads(int n);
+int orc_get_max_threads(void);
 
 #ifdef __cplusplus
 }

@@ -45,6 +45,20 @@ POINT_DTYPE = np.dtype([("pos", "<f4", (3,)), ("quat4", "<f4"), ("radius", "<f4"
 _lib = None
 
 
+def usable_cpus(cap=16):
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    env = os.environ.get("OMP_NUM_THREADS")
+    if env:
+        try:
+            n = min(n, int(env))
+        except ValueError:
+            pass
+    return max(1, min(n, cap))
+
+
 def build():
     subprocess.check_call(["make", "-s", "-C", HERE, "oracle"])
 
@@ -85,6 +99,10 @@ def lib():
         L.orc_final_logp.restype = C.c_double
         L.orc_sizeof_prob_map.restype = C.c_int
         assert L.orc_sizeof_prob_map() == PROB_MAP_DTYPE.itemsize == 40
+        L.orc_set_num_threads.argtypes = [C.c_int]
+        L.orc_get_max_threads.restype = C.c_int
+        # never oversubscribe: the GPU box exposes more hardware threads than this job may use
+        L.orc_set_num_threads(usable_cpus())
         _lib = L
     return _lib
 
