@@ -1618,4 +1618,40 @@ int bioem_hip_reset_kernel_stats(bioem_hip_handle h)
 
 int bioem_hip_uses_fast_path(bioem_hip_handle h) { return h ? h->fast : 0; }
 
+int bioem_hip_r2c(int device, int N, int nImg, const float *in, float *out)
+{
+  if (N < 1 || nImg < 1 || hipSetDevice(device) != hipSuccess)
+    return 1;
+  const int H = N / 2 + 1;
+  const size_t M = (size_t) N * H;
+  std::vector<double2> twd(N);
+  for (int k = 0; k < N; k++)
+  {
+    const double ang = 2.0 * M_PI * (double) k / (double) N;
+    twd[k] = make_double2(cos(ang), sin(ang));
+  }
+  double2 *dTw = nullptr, *dRow = nullptr;
+  float *dIn = nullptr;
+  float2 *dOut = nullptr;
+  int rc = 1;
+  if (hipMalloc(&dTw, sizeof(double2) * N) == hipSuccess && hipMalloc(&dRow, sizeof(double2) * M * nImg) == hipSuccess &&
+      hipMalloc(&dIn, sizeof(float) * (size_t) N * N * nImg) == hipSuccess &&
+      hipMalloc(&dOut, sizeof(float2) * M * nImg) == hipSuccess &&
+      hipMemcpy(dTw, twd.data(), sizeof(double2) * N, hipMemcpyHostToDevice) == hipSuccess &&
+      hipMemcpy(dIn, in, sizeof(float) * (size_t) N * N * nImg, hipMemcpyHostToDevice) == hipSuccess)
+  {
+    hipLaunchKernelGGL(k_dft_rows, dim3(N, nImg), dim3(128), sizeof(double) * N, 0, nullptr, dIn, nullptr, 1.f, N, H,
+                       dTw, dRow);
+    hipLaunchKernelGGL(k_dft_cols, dim3(H, nImg), dim3(256), sizeof(double2) * N, 0, dRow, N, H, dTw, dOut);
+    if (hipGetLastError() == hipSuccess &&
+        hipMemcpy(out, dOut, sizeof(float2) * M * nImg, hipMemcpyDeviceToHost) == hipSuccess)
+      rc = 0;
+  }
+  hipFree(dTw);
+  hipFree(dRow);
+  hipFree(dIn);
+  hipFree(dOut);
+  return rc;
+}
+
 } // extern "C"

@@ -131,6 +131,10 @@ int bioem_hip_finish_run(bioem_hip_handle h, void *pProb_host);
  * the lowest shard (= lowest orientation index, the serial semantics). */
 int bioem_hip_merge_host(int nShards, int nMaps, int nAngles, int writeAngles, const void *const *shards, void *out);
 
+/* Stand-alone forward transform (FFTW r2c convention, [N][N/2+1] (re,im)) of nImg real N x N images on
+ * `device`; replaces the fftwf_execute_dft_r2c call of the PSF kernel set-up (param.cpp:1521). */
+int bioem_hip_r2c(int device, int N, int nImg, const float *in, float *out);
+
 /* ---- instrumentation / test hooks (no reference equivalent) ---- */
 /* projection spectrum of one orientation in reference layout [N][N/2+1][2] */
 int bioem_hip_debug_projection(bioem_hip_handle h, int iOrient, float *spec_out);
