@@ -34,4 +34,83 @@ float bioem_host_center_model(bioem_hip_model_point *pts, int n)
     pts[i] = m.points[i];
   return m.NormDen;
 }
+
+// ------------------------------------------------------------------------------------------------
+// file-level set-up without a device (CTF mode): readParameters + CalculateGridsParam + CalculateRefCTF.
+// Used by the CPU tests to compare the host layer with the oracle's restatement on the golden inputs.
+// Two-call protocol: sizes first (arrays NULL), then the arrays.
+// ------------------------------------------------------------------------------------------------
+struct bioem_host_setup
+{
+  bioem_hip_param_device pd;
+  int nAngles, nCTF, isQuat, usepsf, shiftX, shiftY, nocentermass;
+  float pixelSize, voluang, elecwavel;
+};
+
+int bioem_host_setup_from_files(const char *paramfile, const char *anglefile, bioem_host_setup *out, float *angles4,
+                                float *refCTF, float *ctfParam3)
+{
+  bioem_host::InputParams P;
+  P.notuniformangles = (anglefile && anglefile[0]);
+  P.readParameters(paramfile);
+  P.calculateGridsParam(anglefile ? anglefile : "");
+  out->nAngles = P.nTotGridAngles;
+  out->isQuat = P.doquater;
+  out->usepsf = P.usepsf;
+  out->shiftX = P.shiftX;
+  out->shiftY = P.shiftY;
+  out->nocentermass = P.nocentermass;
+  out->pixelSize = P.pixelSize;
+  out->voluang = P.voluang;
+  out->elecwavel = P.elecwavel;
+  out->nCTF = P.numberGridPointsCTF_amp * P.numberGridPointsCTF_phase * P.numberGridPointsEnvelop;
+  if (!P.usepsf)
+  {
+    P.calculateRefCTF();
+    if (refCTF)
+      for (size_t e = 0; e < P.refCTF.size(); e++)
+        refCTF[e] = P.refCTF[e];
+    if (ctfParam3)
+      for (size_t e = 0; e < P.ctfParam.size(); e++)
+        ctfParam3[e] = P.ctfParam[e];
+  }
+  out->pd = P.pd;
+  if (angles4)
+    for (size_t e = 0; e < P.angles.size(); e++)
+      angles4[e] = P.angles[e];
+  return 0;
+}
+
+// model readers: returns the number of points (fills up to cap), NormDen through *normden
+int bioem_host_read_model(const char *file, int isPDB, int nocentermass, bioem_hip_model_point *pts, int cap,
+                          float *normden)
+{
+  bioem_host::InputParams P;
+  P.nocentermass = nocentermass;
+  P.ignorePDB = true;
+  bioem_host::Model m;
+  m.readPDB = isPDB;
+  m.readModel(P, file);
+  for (int i = 0; i < (int) m.points.size() && i < cap; i++)
+    pts[i] = m.points[i];
+  *normden = m.NormDen;
+  return (int) m.points.size();
+}
+
+// particle readers: mode 0 text, 1 single MRC, 2 list of MRCs; returns the number of images
+int bioem_host_read_particles(const char *file, int mode, int N, int notnormmap, float *maps, int cap)
+{
+  bioem_host::InputParams P;
+  P.N = N;
+  P.notnormmap = notnormmap;
+  bioem_host::ParticleStack S;
+  S.readMRC = mode >= 1;
+  S.readMultMRC = mode == 2;
+  S.readRefMaps(P, file);
+  const size_t sz = (size_t) N * N;
+  for (int i = 0; i < S.ntot && i < cap; i++)
+    for (size_t e = 0; e < sz; e++)
+      maps[(size_t) i * sz + e] = S.maps[(size_t) i * sz + e];
+  return S.ntot;
+}
 }

@@ -54,3 +54,46 @@ def center_model(points):
     pts = np.ascontiguousarray(points.copy())
     nd = load_host_library().bioem_host_center_model(pts.ctypes.data, len(pts))
     return pts, np.float32(nd)
+
+
+class HostSetup(C.Structure):
+    _fields_ = [("pd", ParamDevice), ("nAngles", C.c_int), ("nCTF", C.c_int), ("isQuat", C.c_int),
+                ("usepsf", C.c_int), ("shiftX", C.c_int), ("shiftY", C.c_int), ("nocentermass", C.c_int),
+                ("pixelSize", C.c_float), ("voluang", C.c_float), ("elecwavel", C.c_float)]
+
+
+def setup_from_files(paramfile, anglefile=None):
+    """readParameters + CalculateGridsParam (+ CalculateRefCTF in CTF mode) of the C++ host layer."""
+    L = load_host_library()
+    L.bioem_host_setup_from_files.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(HostSetup), C.c_void_p, C.c_void_p,
+                                              C.c_void_p]
+    S = HostSetup()
+    af = anglefile.encode() if anglefile else None
+    L.bioem_host_setup_from_files(paramfile.encode(), af, C.byref(S), None, None, None)
+    N = S.pd.NumberPixels
+    H = N // 2 + 1
+    angles = np.zeros((S.nAngles, 4), dtype=np.float32)
+    ref = np.zeros((S.nCTF, N, H, 2), dtype=np.float32)
+    par = np.zeros((S.nCTF, 3), dtype=np.float32)
+    L.bioem_host_setup_from_files(paramfile.encode(), af, C.byref(S), angles.ctypes.data, ref.ctypes.data,
+                                  par.ctypes.data)
+    return S, angles, ref, par
+
+
+def read_model(path, isPDB=False, nocentermass=False, cap=1 << 20):
+    L = load_host_library()
+    L.bioem_host_read_model.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_float)]
+    L.bioem_host_read_model.restype = C.c_int
+    pts = np.zeros(cap, dtype=POINT_DTYPE)
+    nd = C.c_float()
+    n = L.bioem_host_read_model(path.encode(), int(isPDB), int(nocentermass), pts.ctypes.data, cap, C.byref(nd))
+    return pts[:n].copy(), np.float32(nd.value)
+
+
+def read_particles(path, N, mode=0, notnormmap=False, cap=4096):
+    L = load_host_library()
+    L.bioem_host_read_particles.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int]
+    L.bioem_host_read_particles.restype = C.c_int
+    maps = np.zeros((cap, N, N), dtype=np.float32)
+    n = L.bioem_host_read_particles(path.encode(), mode, N, int(notnormmap), maps.ctypes.data, cap)
+    return maps[:n].copy()

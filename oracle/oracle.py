@@ -253,6 +253,15 @@ def parse_param_file(path):
     return P
 
 
+_libm = C.CDLL("libm.so.6")
+_libm.acosf.argtypes = [C.c_float]
+_libm.acosf.restype = C.c_float
+
+
+def _libm_acosf(x):
+    return _libm.acosf(float(x))
+
+
 def orientations(P, orient_lines=None):
     """param.cpp:988-1334.  Returns (angles[n,4] f32, isQuat, voluang f32)."""
     priorMod = P["priorMod"]
@@ -278,7 +287,7 @@ def orientations(P, orient_lines=None):
                     # :1031-1039: float*float - double + float -> double -> float
                     ang[n, 0] = f32(float(f32(ia) * grid_alpha) - math.pi + float(grid_alpha * f32(0.5)))
                     carg = f32(f32(ib) * cos_grid_beta) - f32(1) + cos_grid_beta * f32(0.5)
-                    ang[n, 1] = f32(np.arccos(f32(carg)))
+                    ang[n, 1] = f32(_libm_acosf(f32(carg)))  # float overload of acos = libm acosf
                     ang[n, 2] = f32(float(f32(ig) * grid_alpha) - math.pi + float(grid_alpha * f32(0.5)))
                     n += 1
         # :1046-1047
