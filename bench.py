@@ -164,6 +164,17 @@ def main():
                      "alg_bytes_per_comparison": b_alg,
                      "comparisons_per_launch": (ncomp / launches) if launches else None},
     }
+    # HBM traffic of the same kernel on the same per-launch workload from the committed rocprofv3 PMC passes
+    # (profiles/pmc_traffic.json, collected in separate --pmc runs; cannot be sampled inside this process)
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+            pmc = json.load(f)
+        if launches and abs(ncomp / launches - pmc["comparisons_per_launch"]) < 1 and W.N == 224:
+            out["roofline"]["traffic"] = pmc["traffic_bytes_per_launch"] / 1e9 / (kms / launches / 1e3)
+            out["roofline"]["traffic_bytes_per_launch"] = pmc["traffic_bytes_per_launch"]
+            out["roofline"]["traffic_source"] = "profiles/%s_pmc_summary.json" % pmc["tag"]
+    except (OSError, KeyError, ValueError):
+        pass
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         sys.path.insert(0, os.path.join(ROOT, "oracle"))
         import oracle as orc
