@@ -99,6 +99,7 @@ struct bioem_hip_ctx
   float2 *dTw = nullptr;   // N+1 entries exp(+2 pi i k/N), float
   double2 *dTwD = nullptr; // N entries, double
   int *dDisp = nullptr;
+  double2 *dLtab = nullptr;
 
   double *dProjReal = nullptr; // [chunkB][N*N]
   double *dTempDen = nullptr;  // [chunkB]
@@ -634,43 +635,100 @@ struct CompareArgs
   const float *sumRef, *sumsqRef;
   const float2 *tw; // N+1
   const int *disp;  // nd
+  const double2 *ltab; // 64 x {c, -log c}
   Partial *partials; // [nMaps][ldPart]
   int ldPart;
   int N, H, N1, nd, maxD, nOC, nMaps, algo;
   PD pd;
 };
 
-// Evaluate the displacement window from the column transforms T (LDS, [row = dx + WD][Hs] float2, already
-// weighted by 1 or 2 per column) and reduce to this wave's partial.
-// lane = (iy, group); a group owns up to NR consecutive displacement rows, so each twiddle E[ky*dy] read
-// from LDS feeds NR accumulators.
-template <int WD, int NR>
-__device__ __forceinline__ void window_eval(const CompareArgs &a, const float2 *Tl, int Hs, const float2 *twl,
-                                            const int *displ, const bioem_hip_param5 &q, float sumref,
-                                            float sumsqref, Lse &L)
+// ------------------------------------------------------------------------------------------------
+// log of a positive float in double precision, cheap: f = m * 2^e, m in [1,2); c ~ 1/m from a 64-entry
+// table, r = m*c - 1 exactly rounded by one fma (|r| <= 2^-7), log f = e ln2 - log c + log1p(r) with a
+// degree-6 Taylor polynomial (truncation 2^-49/7).  Absolute error ~1e-15, i.e. < 3e-11 after the
+// (3-Np)/2 amplification -- far below the float narrowing the reference applies to logpro.
+// Table entry = {c, -log(c)} in LDS.
+// ------------------------------------------------------------------------------------------------
+__device__ __noinline__ double log_slow_path(float f) { return log((double) f); }
+
+__device__ __forceinline__ double log_of_float(float f, const double2 *ltab)
 {
-  const int lane = threadIdx.x & 63;
-  const int nd = a.nd, N = a.N;
-  const int G = 64 / nd;
-  const int nr = (nd + G - 1) / G;
-  const int iy = lane % nd, grp = lane / nd;
-  const bool active = grp < G;
-  const int dy = displ[iy];
-  const int step = dy < 0 ? dy + N : dy;
-  float acc[NR];
-  int rowoff[NR];
-#pragma unroll
-  for (int r = 0; r < NR; r++)
+  const unsigned int bits = __float_as_uint(f);
+  if (!(f > 1.1754944e-38f) || bits >= 0x7f800000u) // zero, negative, subnormal, inf, nan: exact slow path
+    return log_slow_path(f);
+  const int e = (int) (bits >> 23) - 127;
+  const float m = __uint_as_float((bits & 0x007fffffu) | 0x3f800000u);
+  const double2 t = ltab[(bits >> 17) & 63];
+  const double r = fma((double) m, t.x, -1.0);
+  double p = fma(r, -1.0 / 6.0, 1.0 / 5.0);
+  p = fma(r, p, -1.0 / 4.0);
+  p = fma(r, p, 1.0 / 3.0);
+  p = fma(r, p, -1.0 / 2.0);
+  p = fma(r * r, p, r);
+  return fma((double) e, 0.693147180559945309417232, t.y + p);
+}
+
+// exp of a non-positive double difference through the hardware exp2 (relative error ~2e-7 per term; the
+// terms are summed in double, so log(Total) moves by < 1e-6)
+__device__ __forceinline__ double exp_fast_nonpos(double x) { return (double) __expf((float) x); }
+
+struct LseF
+{
+  float m;
+  double s;
+  int id;
+  float val;
+};
+
+__device__ __forceinline__ void lsef_push(LseF &L, double lp, int id, float val, int algo)
+{
+  const float lpf = (float) lp;
+  const double lpe = (algo == 1) ? (double) lpf : lp;
+  if (L.m < lpf)
   {
-    acc[r] = 0.f;
-    int ix = grp * nr + r;
-    if (ix >= nd)
-      ix = nd - 1;
-    rowoff[r] = (displ[ix] + WD) * Hs;
+    L.s = (L.m == -INFINITY) ? 0. : L.s * exp_fast_nonpos((double) L.m - (double) lpf);
+    L.m = lpf;
+    L.id = id;
+    L.val = val;
   }
-  int idx = 0;
-  const int H2 = Hs >> 1;
-  for (int kp = 0; kp < H2; kp++)
+  L.s += exp_fast_nonpos(lpe - (double) L.m);
+}
+
+__device__ __forceinline__ void lsef_wave_reduce(LseF &L)
+{
+  for (int off = 32; off > 0; off >>= 1)
+  {
+    const float m2 = __shfl_xor(L.m, off);
+    const double s2 = __shfl_xor(L.s, off);
+    const int id2 = __shfl_xor(L.id, off);
+    const float v2 = __shfl_xor(L.val, off);
+    if (m2 > L.m || (m2 == L.m && id2 < L.id))
+    {
+      const double sc = (L.m == -INFINITY) ? 0. : L.s * exp_fast_nonpos((double) L.m - (double) m2);
+      L.s = sc + s2;
+      L.m = m2;
+      L.id = id2;
+      L.val = v2;
+    }
+    else
+    {
+      const double sc = (m2 == -INFINITY) ? 0. : s2 * exp_fast_nonpos((double) m2 - (double) L.m);
+      L.s += sc;
+    }
+  }
+}
+
+// Window accumulation over one block of 64 frequency columns held in LDS as Tl[row = dx + WD][64] float2
+// (already weighted by 1 or 2 per column; zero beyond H).  lane = (iy, group); a group owns `nr` consecutive
+// displacement rows so that each LDS twiddle read E[ky*dy] feeds nr accumulators; T is read two columns
+// at a time (ds_read_b128).  STATIC: nr == NR known at compile time (the +-10 px, grid 1 case).
+template <int NR, bool STATIC>
+__device__ __forceinline__ void window_accumulate(const float2 *Tl, const float2 *twl, int N, int step, int idx0,
+                                                  const int (&rowoff)[NR], int nr, float (&acc)[NR])
+{
+  int idx = idx0;
+#pragma unroll 2
+  for (int kp = 0; kp < 32; kp++)
   {
     const float2 w0 = twl[idx];
     idx += step;
@@ -683,28 +741,16 @@ __device__ __forceinline__ void window_eval(const CompareArgs &a, const float2 *
 #pragma unroll
     for (int r = 0; r < NR; r++)
     {
-      if (r < nr)
+      if (STATIC || r < nr)
       {
         const float4 t = *reinterpret_cast<const float4 *>(&Tl[rowoff[r] + 2 * kp]);
-        acc[r] = fmaf(t.x, w0.x, acc[r]);
-        acc[r] = fmaf(-t.y, w0.y, acc[r]);
-        acc[r] = fmaf(t.z, w1.x, acc[r]);
-        acc[r] = fmaf(-t.w, w1.y, acc[r]);
+        float v = acc[r];
+        v = fmaf(t.x, w0.x, v);
+        v = fmaf(-t.y, w0.y, v);
+        v = fmaf(t.z, w1.x, v);
+        v = fmaf(-t.w, w1.y, v);
+        acc[r] = v;
       }
-    }
-  }
-  double t2, prior;
-  logpro_consts(a.pd, q, t2, prior);
-  const float nn = (float) (N * N);
-#pragma unroll
-  for (int r = 0; r < NR; r++)
-  {
-    const int ix = grp * nr + r;
-    if (r < nr && active && ix < nd)
-    {
-      const float value = acc[r] / nn;
-      const double lp = logpro_eval(a.pd, q, value, sumref, sumsqref, t2, prior);
-      lse_push(L, lp, ix * nd + iy, value, a.algo);
     }
   }
 }
@@ -713,7 +759,9 @@ __device__ __forceinline__ void window_eval(const CompareArgs &a, const float2 *
 // fast comparison kernel: N = 32*N1, 2*maxD+1 <= 2*WD+1 <= 31.
 // block = 4 waves = 4 consecutive (orientation*CTF) indices of ONE particle (the particle columns are then
 // served to waves 1..3 from L1); blockIdx.x = ocGroup * nMaps + particle, so concurrently resident blocks
-// share the same 4 conv spectra in L2.
+// share the same 4 conv spectra in L2.  Columns are processed in blocks of 64 (lane = column): register
+// FFTs -> T block in LDS -> window accumulation, so the LDS footprint per wave is (2*WD+1)*64*8 bytes
+// (10.5 KiB for +-10 px => 3 blocks per CU, matching the VGPR-limited 3 waves per SIMD).
 // ------------------------------------------------------------------------------------------------
 template <int WD>
 __global__ __launch_bounds__(256) void k_compare_fast(const CompareArgs a)
@@ -722,17 +770,20 @@ __global__ __launch_bounds__(256) void k_compare_fast(const CompareArgs a)
   constexpr int NR = (WD <= 10) ? 7 : 16;
   extern __shared__ __align__(16) unsigned char smem[];
   const int N = a.N, H = a.H, N1 = a.N1;
-  const int Hs = (H + 1) & ~1;
-  float2 *twl = reinterpret_cast<float2 *>(smem);                        // N+1 (+pad)
-  int *displ = reinterpret_cast<int *>(smem + (size_t) ((N + 2) & ~1) * 8); // nd ints (64 reserved)
-  float2 *Tall = reinterpret_cast<float2 *>(smem + (size_t) ((N + 2) & ~1) * 8 + 256);
+  float2 *twl = reinterpret_cast<float2 *>(smem);                            // N+1 (+pad)
+  int *displ = reinterpret_cast<int *>(smem + (size_t) ((N + 2) & ~1) * 8); // nd ints (256 B reserved)
+  double2 *ltab = reinterpret_cast<double2 *>(smem + (size_t) ((N + 2) & ~1) * 8 + 256); // 64 entries
+  float2 *Tall = reinterpret_cast<float2 *>(smem + (size_t) ((N + 2) & ~1) * 8 + 256 + 1024);
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  float2 *Tl = Tall + (size_t) wave * NW * Hs;
+  float2 *Tl = Tall + (size_t) wave * NW * 64;
 
   for (int t = threadIdx.x; t <= N; t += blockDim.x)
     twl[t] = a.tw[t];
   for (int t = threadIdx.x; t < a.nd; t += blockDim.x)
     displ[t] = a.disp[t];
+  for (int t = threadIdx.x; t < 64; t += blockDim.x)
+    ltab[t] = a.ltab[t];
+  __syncthreads();
 
   const int p = blockIdx.x % a.nMaps;
   const int ocg = blockIdx.x / a.nMaps;
@@ -743,10 +794,31 @@ __global__ __launch_bounds__(256) void k_compare_fast(const CompareArgs a)
   const float4 *F4 = reinterpret_cast<const float4 *>(a.ref + (size_t) p * M);
   const float4 *C4 = reinterpret_cast<const float4 *>(a.conv + (size_t) oc * M);
 
-  const int nhalf = (Hs + 63) / 64;
-  for (int half = 0; half < nhalf; half++)
+  // window lanes
+  const int nd = a.nd;
+  const int G = 64 / nd;
+  const int nr = (nd + G - 1) / G;
+  const int iy = lane % nd, grp = lane / nd;
+  const bool wactive = grp < G;
+  const int dy = displ[iy];
+  const int step = dy < 0 ? dy + N : dy;
+  const bool is_static = (nr == NR);
+  float acc[NR];
+  int rowoff[NR];
+#pragma unroll
+  for (int r = 0; r < NR; r++)
   {
-    const int ky = half * 64 + lane;
+    acc[r] = 0.f;
+    int ix = grp * nr + r;
+    if (ix >= nd)
+      ix = nd - 1;
+    rowoff[r] = (displ[ix] + WD) * 64;
+  }
+
+  const int nblk = (H + 63) / 64;
+  for (int blk = 0; blk < nblk; blk++)
+  {
+    const int ky = blk * 64 + lane;
     const int kyc = ky < H ? ky : H - 1;
     float Tr[NW], Ti[NW];
 #pragma unroll
@@ -777,7 +849,7 @@ __global__ __launch_bounds__(256) void k_compare_fast(const CompareArgs a)
       for (int d = -WD; d <= WD; d++)
       {
         const int pos = bitrev5(d & 31);
-        const int tix = d >= 0 ? d * k1 : N + d * k1; // uniform; table has N+1 entries
+        const int tix = d >= 0 ? d * k1 : N + d * k1; // wave-uniform; table has N+1 entries
         const float2 w = a.tw[tix];
         float tr = Tr[d + WD], ti = Ti[d + WD];
         tr = fmaf(xr[pos], w.x, tr);
@@ -794,20 +866,46 @@ __global__ __launch_bounds__(256) void k_compare_fast(const CompareArgs a)
       wgt = 1.f;
     if (ky >= H)
       wgt = 0.f;
-    if (ky < Hs)
-    {
+    __syncthreads(); // previous block's window reads are done
 #pragma unroll
-      for (int d = 0; d < NW; d++)
-        Tl[d * Hs + ky] = make_float2(Tr[d] * wgt, Ti[d] * wgt);
-    }
+    for (int d = 0; d < NW; d++)
+      Tl[d * 64 + lane] = make_float2(Tr[d] * wgt, Ti[d] * wgt);
+    __syncthreads();
+    const int idx0 = (int) (((long long) blk * 64 * step) % N);
+    if (is_static)
+      window_accumulate<NR, true>(Tl, twl, N, step, idx0, rowoff, nr, acc);
+    else
+      window_accumulate<NR, false>(Tl, twl, N, step, idx0, rowoff, nr, acc);
   }
-  __syncthreads();
 
   const bioem_hip_param5 q = a.params[oc];
-  Lse L;
-  lse_init(L);
-  window_eval<WD, NR>(a, Tl, Hs, twl, displ, q, a.sumRef[p], a.sumsqRef[p], L);
-  lse_wave_reduce(L);
+  const float sumref = a.sumRef[p], sumsqref = a.sumsqRef[p];
+  double t2, prior;
+  logpro_consts(a.pd, q, t2, prior);
+  const float Np = a.pd.Ntotpi;
+  const double A = (double) (3 - Np) * 0.5;
+  const float nn = (float) (N * N);
+  LseF L;
+  L.m = -INFINITY;
+  L.s = 0.;
+  L.id = 0x7fffffff;
+  L.val = 0.f;
+#pragma unroll
+  for (int r = 0; r < NR; r++)
+  {
+    const int ix = grp * nr + r;
+    if (r < nr && wactive && ix < nd)
+    {
+      const float cc = acc[r] / nn;
+      // bioem_algorithm.h:32-36, float expression in the reference's order
+      const float firstele = Np * (sumsqref * q.sumsquareC - cc * cc) + 2 * sumref * q.sumC * cc -
+                             sumsqref * q.sumC * q.sumC - sumref * sumref * q.sumsquareC;
+      double lp = A * log_of_float(firstele, ltab) + t2;
+      lp -= prior;
+      lsef_push(L, lp, ix * nd + iy, cc, a.algo);
+    }
+  }
+  lsef_wave_reduce(L);
   if (lane == 0 && oc_valid)
   {
     Partial r;
@@ -980,9 +1078,14 @@ __global__ void k_fold(const Partial *__restrict__ partials, int ldPart, int nOC
 // host helpers
 // ------------------------------------------------------------------------------------------------
 size_t compare_lds_bytes(int N, int H, int NW, int waves)
-{
+{ // generic kernel: tables + per-wave T [NW][Hs]
   const int Hs = (H + 1) & ~1;
   return (size_t) ((N + 2) & ~1) * 8 + 256 + (size_t) waves * NW * Hs * 8;
+}
+
+size_t fast_lds_bytes(int N, int NW, int waves)
+{ // fast kernel: twiddles + displacement list + log table + per-wave T block [NW][64]
+  return (size_t) ((N + 2) & ~1) * 8 + 256 + 1024 + (size_t) waves * NW * 64 * 8;
 }
 
 hipEvent_t get_event(bioem_hip_ctx *h)
@@ -1022,6 +1125,7 @@ int launch_compare_fold(bioem_hip_ctx *h, int nOC, int orient0, int conv0, int c
   a.sumsqRef = h->dSumsqRef;
   a.tw = h->dTw;
   a.disp = h->dDisp;
+  a.ltab = h->dLtab;
   a.partials = h->dPartials;
   a.ldPart = h->maxOC;
   a.N = h->N;
@@ -1045,7 +1149,7 @@ int launch_compare_fold(bioem_hip_ctx *h, int nOC, int orient0, int conv0, int c
   if (h->fast)
   {
     const int NW = 2 * h->winD + 1;
-    const size_t lds = compare_lds_bytes(h->N, h->H, NW, 4);
+    const size_t lds = fast_lds_bytes(h->N, NW, 4);
     if (h->winD == 10)
       hipLaunchKernelGGL(k_compare_fast<10>, grid, dim3(256), lds, h->stream, a);
     else
@@ -1179,17 +1283,11 @@ int bioem_hip_create(bioem_hip_handle *out, int device, const bioem_hip_param_de
     h->winD = 15;
   // LDS budget check
   {
-    const int NW = h->fast ? 2 * h->winD + 1 : 2 * maxD + 1;
-    const size_t lds = compare_lds_bytes(N, h->H, NW, 4);
+    const size_t lds = h->fast ? fast_lds_bytes(N, 2 * h->winD + 1, 4) : compare_lds_bytes(N, h->H, 2 * maxD + 1, 4);
     if (lds > 160 * 1024)
     {
-      if (h->fast && compare_lds_bytes(N, h->H, 2 * maxD + 1, 4) <= 160 * 1024)
-        h->fast = 0;
-      else
-      {
-        h->err = "configuration exceeds the 160 KiB LDS budget of the comparison kernel";
-        return 2;
-      }
+      h->err = "configuration exceeds the 160 KiB LDS budget of the comparison kernel";
+      return 2;
     }
     if (h->fast)
     {
@@ -1234,6 +1332,7 @@ int bioem_hip_create(bioem_hip_handle *out, int device, const bioem_hip_param_de
   HIP_CHECK(h, hipMalloc(&h->dTw, sizeof(float2) * (N + 1)));
   HIP_CHECK(h, hipMalloc(&h->dTwD, sizeof(double2) * N));
   HIP_CHECK(h, hipMalloc(&h->dDisp, sizeof(int) * h->nd));
+  HIP_CHECK(h, hipMalloc(&h->dLtab, sizeof(double2) * 64));
   HIP_CHECK(h, hipMalloc(&h->dProjReal, sizeof(double) * (size_t) h->chunkB * N * N));
   HIP_CHECK(h, hipMalloc(&h->dTempDen, sizeof(double) * h->chunkB));
   HIP_CHECK(h, hipMalloc(&h->dRowSpec, sizeof(double2) * (size_t) h->chunkB * M));
@@ -1257,6 +1356,16 @@ int bioem_hip_create(bioem_hip_handle *out, int device, const bioem_hip_param_de
   HIP_CHECK(h, hipMemcpy(h->dTw, tw.data(), sizeof(float2) * (N + 1), hipMemcpyHostToDevice));
   HIP_CHECK(h, hipMemcpy(h->dTwD, twd.data(), sizeof(double2) * N, hipMemcpyHostToDevice));
   HIP_CHECK(h, hipMemcpy(h->dDisp, h->disp.data(), sizeof(int) * h->nd, hipMemcpyHostToDevice));
+  {
+    // log table: bin i of the mantissa interval [1,2): c = 1/centre, entry {c, -log(c)}
+    std::vector<double2> lt(64);
+    for (int i = 0; i < 64; i++)
+    {
+      const double c = 1.0 / (1.0 + ((double) i + 0.5) / 64.0);
+      lt[i] = make_double2(c, -log(c));
+    }
+    HIP_CHECK(h, hipMemcpy(h->dLtab, lt.data(), sizeof(double2) * 64, hipMemcpyHostToDevice));
+  }
   HIP_CHECK(h, hipEventCreateWithFlags(&h->slotEvent[0], hipEventDisableTiming));
   HIP_CHECK(h, hipEventCreateWithFlags(&h->slotEvent[1], hipEventDisableTiming));
   return 0;
@@ -1273,7 +1382,7 @@ int bioem_hip_destroy(bioem_hip_handle h)
   for (hipEvent_t e : h->evPool)
     hipEventDestroy(e);
   void *ptrs[] = {h->dRef,     h->dSumRef,  h->dSumsqRef, h->dCTF,     h->dCtfParam, h->dPts,   h->dAngles,
-                  h->dTw,      h->dTwD,     h->dDisp,     h->dProjReal, h->dTempDen,  h->dRowSpec, h->dSpecRef,
+                  h->dTw,      h->dTwD,     h->dDisp,     h->dLtab,    h->dProjReal, h->dTempDen,  h->dRowSpec, h->dSpecRef,
                   h->dScratch, h->dConv,    h->dParams,   h->dPartials, h->dProb,     h->dStage};
   for (void *p : ptrs)
     if (p)
