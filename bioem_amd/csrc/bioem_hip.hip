@@ -100,6 +100,7 @@ struct bioem_hip_ctx
   double2 *dTwD = nullptr; // N entries, double
   int *dDisp = nullptr;
   double2 *dLtab = nullptr;
+  float2 *dTwk = nullptr;
 
   double *dProjReal = nullptr; // [chunkB][N*N]
   double *dTempDen = nullptr;  // [chunkB]
@@ -627,6 +628,13 @@ __device__ __forceinline__ void fft32_inverse(float (&xr)[32], float (&xi)[32])
   }
 }
 
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float4 as_float4(u32x4 v)
+{
+  return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}
+
 struct CompareArgs
 {
   const float2 *ref;  // [nMaps][M] comparison layout
@@ -636,6 +644,7 @@ struct CompareArgs
   const float2 *tw; // N+1
   const int *disp;  // nd
   const double2 *ltab; // 64 x {c, -log c}
+  const float2 *twk;   // [N1][2*WD+1] recombination twiddles exp(2 pi i d k1 / N), d = -WD..WD
   Partial *partials; // [nMaps][ldPart]
   int ldPart;
   int N, H, N1, nd, maxD, nOC, nMaps, algo;
@@ -763,19 +772,25 @@ __device__ __forceinline__ void window_accumulate(const float2 *Tl, const float2
 // FFTs -> T block in LDS -> window accumulation, so the LDS footprint per wave is (2*WD+1)*64*8 bytes
 // (10.5 KiB for +-10 px => 3 blocks per CU, matching the VGPR-limited 3 waves per SIMD).
 // ------------------------------------------------------------------------------------------------
+#ifndef BIOEM_FAST_WAVES_PER_SIMD
+#define BIOEM_FAST_WAVES_PER_SIMD 3
+#endif
 template <int WD>
-__global__ __launch_bounds__(256) void k_compare_fast(const CompareArgs a)
+__global__ __launch_bounds__(256, BIOEM_FAST_WAVES_PER_SIMD) void k_compare_fast(const CompareArgs a)
 {
   constexpr int NW = 2 * WD + 1;
   constexpr int NR = (WD <= 10) ? 7 : 16;
+  constexpr int TS = 66; // T row stride in float2 (64 columns + 2 pad: row groups land on different banks)
   extern __shared__ __align__(16) unsigned char smem[];
   const int N = a.N, H = a.H, N1 = a.N1;
   float2 *twl = reinterpret_cast<float2 *>(smem);                            // N+1 (+pad)
   int *displ = reinterpret_cast<int *>(smem + (size_t) ((N + 2) & ~1) * 8); // nd ints (256 B reserved)
   double2 *ltab = reinterpret_cast<double2 *>(smem + (size_t) ((N + 2) & ~1) * 8 + 256); // 64 entries
   float2 *Tall = reinterpret_cast<float2 *>(smem + (size_t) ((N + 2) & ~1) * 8 + 256 + 1024);
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  float2 *Tl = Tall + (size_t) wave * NW * 64;
+  // wave index made provably uniform (SGPR) so that per-wave base pointers use scalar addressing
+  const int wave = __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6));
+  const int lane = threadIdx.x & 63;
+  float2 *Tl = Tall + (size_t) wave * NW * TS;
 
   for (int t = threadIdx.x; t <= N; t += blockDim.x)
     twl[t] = a.tw[t];
@@ -791,8 +806,11 @@ __global__ __launch_bounds__(256) void k_compare_fast(const CompareArgs a)
   const bool oc_valid = oc_raw < a.nOC;
   const int oc = oc_valid ? oc_raw : a.nOC - 1;
   const size_t M = (size_t) N * H;
-  const float4 *F4 = reinterpret_cast<const float4 *>(a.ref + (size_t) p * M);
-  const float4 *C4 = reinterpret_cast<const float4 *>(a.conv + (size_t) oc * M);
+  // buffer descriptors built from wave-uniform values only (blockIdx / readfirstlane'd wave id)
+  const auto rsrcF = __builtin_amdgcn_make_buffer_rsrc(const_cast<float2 *>(a.ref + (size_t) p * M), 0,
+                                                       (int) (M * sizeof(float2)), 0x00020000);
+  const auto rsrcC = __builtin_amdgcn_make_buffer_rsrc(const_cast<float2 *>(a.conv + (size_t) oc * M), 0,
+                                                       (int) (M * sizeof(float2)), 0x00020000);
 
   // window lanes
   const int nd = a.nd;
@@ -812,7 +830,7 @@ __global__ __launch_bounds__(256) void k_compare_fast(const CompareArgs a)
     int ix = grp * nr + r;
     if (ix >= nd)
       ix = nd - 1;
-    rowoff[r] = (displ[ix] + WD) * 64;
+    rowoff[r] = (displ[ix] + WD) * TS;
   }
 
   const int nblk = (H + 63) / 64;
@@ -827,20 +845,45 @@ __global__ __launch_bounds__(256) void k_compare_fast(const CompareArgs a)
       Tr[d] = 0.f;
       Ti[d] = 0.f;
     }
+    // Software-pipelined operand stream: the (k1, k2-pair) loads of this lane walk t = k1*16 + k2p with a
+    // constant stride of H float4; a 4-deep ring of (F, C) pairs keeps 8 dwordx4 loads (8 KiB per wave) in
+    // flight, re-issued as soon as a slot is consumed -- also across the FFT of the previous k1.
+    // addressing: buffer loads -- 128-bit descriptor (SGPRs) of this particle / conv spectrum, one constant
+    // 32-bit lane offset (VGPR) and the row offset t*H*16 in an SGPR: no vector address arithmetic at all.
+    const int ttotal = 16 * N1;
+    const unsigned laneoff = (unsigned) kyc * 16u;
+    const unsigned rowbytes = (unsigned) H * 16u;
+    u32x4 rf[4], rc[4];
+#pragma unroll
+    for (int t = 0; t < 4; t++)
+    {
+      rf[t] = __builtin_amdgcn_raw_buffer_load_b128(rsrcF, laneoff, (unsigned) t * rowbytes, 0);
+      rc[t] = __builtin_amdgcn_raw_buffer_load_b128(rsrcC, laneoff, (unsigned) t * rowbytes, 0);
+    }
     for (int k1 = 0; k1 < N1; k1++)
     {
       float xr[32], xi[32];
-      const size_t base = (size_t) (k1 * 16) * H + kyc;
+      // the 2*WD+1 recombination twiddles of this k1 are contiguous: a few wide scalar loads, issued early
+      float2 wk[NW];
+      const float2 *twk = a.twk + (size_t) k1 * NW;
+#pragma unroll
+      for (int d = 0; d < NW; d++)
+        wk[d] = twk[d];
 #pragma unroll
       for (int k2p = 0; k2p < 16; k2p++)
       {
-        const float4 f = F4[base + (size_t) k2p * H];
-        const float4 c = C4[base + (size_t) k2p * H];
+        const float4 f = as_float4(rf[k2p & 3]);
+        const float4 c = as_float4(rc[k2p & 3]);
         // X = conv * conj(ref)   (bioem.cpp:1452-1455)
         xr[2 * k2p] = fmaf(c.x, f.x, c.y * f.y);
         xi[2 * k2p] = fmaf(c.y, f.x, -(c.x * f.y));
         xr[2 * k2p + 1] = fmaf(c.z, f.z, c.w * f.w);
         xi[2 * k2p + 1] = fmaf(c.w, f.z, -(c.z * f.w));
+        int tn = k1 * 16 + k2p + 4;
+        tn = tn < ttotal ? tn : ttotal - 1;
+        rf[k2p & 3] = __builtin_amdgcn_raw_buffer_load_b128(rsrcF, laneoff, (unsigned) tn * rowbytes, 0);
+        rc[k2p & 3] = __builtin_amdgcn_raw_buffer_load_b128(rsrcC, laneoff, (unsigned) tn * rowbytes, 0);
+        __builtin_amdgcn_sched_barrier(0);
       }
       fft32_inverse(xr, xi);
       // recombination of the N1 sub-transforms for the displacement window only:
@@ -849,8 +892,7 @@ __global__ __launch_bounds__(256) void k_compare_fast(const CompareArgs a)
       for (int d = -WD; d <= WD; d++)
       {
         const int pos = bitrev5(d & 31);
-        const int tix = d >= 0 ? d * k1 : N + d * k1; // wave-uniform; table has N+1 entries
-        const float2 w = a.tw[tix];
+        const float2 w = wk[d + WD];
         float tr = Tr[d + WD], ti = Ti[d + WD];
         tr = fmaf(xr[pos], w.x, tr);
         tr = fmaf(-xi[pos], w.y, tr);
@@ -869,7 +911,7 @@ __global__ __launch_bounds__(256) void k_compare_fast(const CompareArgs a)
     __syncthreads(); // previous block's window reads are done
 #pragma unroll
     for (int d = 0; d < NW; d++)
-      Tl[d * 64 + lane] = make_float2(Tr[d] * wgt, Ti[d] * wgt);
+      Tl[d * TS + lane] = make_float2(Tr[d] * wgt, Ti[d] * wgt);
     __syncthreads();
     const int idx0 = (int) (((long long) blk * 64 * step) % N);
     if (is_static)
@@ -1085,7 +1127,7 @@ size_t compare_lds_bytes(int N, int H, int NW, int waves)
 
 size_t fast_lds_bytes(int N, int NW, int waves)
 { // fast kernel: twiddles + displacement list + log table + per-wave T block [NW][64]
-  return (size_t) ((N + 2) & ~1) * 8 + 256 + 1024 + (size_t) waves * NW * 64 * 8;
+  return (size_t) ((N + 2) & ~1) * 8 + 256 + 1024 + (size_t) waves * NW * 66 * 8;
 }
 
 hipEvent_t get_event(bioem_hip_ctx *h)
@@ -1126,6 +1168,7 @@ int launch_compare_fold(bioem_hip_ctx *h, int nOC, int orient0, int conv0, int c
   a.tw = h->dTw;
   a.disp = h->dDisp;
   a.ltab = h->dLtab;
+  a.twk = h->dTwk;
   a.partials = h->dPartials;
   a.ldPart = h->maxOC;
   a.N = h->N;
@@ -1366,6 +1409,19 @@ int bioem_hip_create(bioem_hip_handle *out, int device, const bioem_hip_param_de
     }
     HIP_CHECK(h, hipMemcpy(h->dLtab, lt.data(), sizeof(double2) * 64, hipMemcpyHostToDevice));
   }
+  if (h->fast)
+  {
+    const int NW = 2 * h->winD + 1;
+    std::vector<float2> twk((size_t) h->N1 * NW);
+    for (int k1 = 0; k1 < h->N1; k1++)
+      for (int d = -h->winD; d <= h->winD; d++)
+      {
+        const double ang = 2.0 * M_PI * (double) (((d * k1) % N + N) % N) / (double) N;
+        twk[(size_t) k1 * NW + d + h->winD] = make_float2((float) cos(ang), (float) sin(ang));
+      }
+    HIP_CHECK(h, hipMalloc(&h->dTwk, sizeof(float2) * twk.size()));
+    HIP_CHECK(h, hipMemcpy(h->dTwk, twk.data(), sizeof(float2) * twk.size(), hipMemcpyHostToDevice));
+  }
   HIP_CHECK(h, hipEventCreateWithFlags(&h->slotEvent[0], hipEventDisableTiming));
   HIP_CHECK(h, hipEventCreateWithFlags(&h->slotEvent[1], hipEventDisableTiming));
   return 0;
@@ -1382,7 +1438,7 @@ int bioem_hip_destroy(bioem_hip_handle h)
   for (hipEvent_t e : h->evPool)
     hipEventDestroy(e);
   void *ptrs[] = {h->dRef,     h->dSumRef,  h->dSumsqRef, h->dCTF,     h->dCtfParam, h->dPts,   h->dAngles,
-                  h->dTw,      h->dTwD,     h->dDisp,     h->dLtab,    h->dProjReal, h->dTempDen,  h->dRowSpec, h->dSpecRef,
+                  h->dTw,      h->dTwD,     h->dDisp,     h->dLtab,    h->dTwk,     h->dProjReal, h->dTempDen,  h->dRowSpec, h->dSpecRef,
                   h->dScratch, h->dConv,    h->dParams,   h->dPartials, h->dProb,     h->dStage};
   for (void *p : ptrs)
     if (p)
