@@ -113,6 +113,19 @@ struct bioem_hip_ctx
   unsigned char *dProb = nullptr;
   size_t probBytes = 0;
 
+  // second buffer set + stream: projection/convolution of batch k+1 overlap the comparison of batch k
+  hipStream_t prepStream = nullptr;
+  double *dProjReal2 = nullptr;
+  double *dTempDen2 = nullptr;
+  double2 *dRowSpec2 = nullptr;
+  float2 *dSpecRef2 = nullptr;
+  float *dScratch2 = nullptr;
+  float2 *dConv2 = nullptr;
+  bioem_hip_param5 *dParams2 = nullptr;
+  hipEvent_t prepDone[2] = {nullptr, nullptr};
+  hipEvent_t cmpDone[2] = {nullptr, nullptr};
+  bool cmpPending[2] = {false, false};
+
   // compat entry staging
   float2 *hStage = nullptr;
   float2 *dStage = nullptr;
@@ -277,11 +290,15 @@ __global__ void k_project(const bioem_hip_model_point *__restrict__ pts, int nPt
 // rows: src is either the double projection map scaled by NormDen/tempden in float (bioem.cpp:1808-1818)
 //       or float particle maps.
 // ------------------------------------------------------------------------------------------------
+// Both passes use one Cooley-Tukey split N = A*B (A the largest divisor <= sqrt(N); A = 1 for prime N):
+//   Y[j1][kb] = sum_{j2<B} x[A*j2 + j1] * w_B^(j2*kb),   X[k] = sum_{j1<A} w_N^(j1*k) * Y[j1][k mod B]
+// i.e. N*(A+B) instead of N*N terms per 1-D transform, still exact-DFT arithmetic in double.
 __global__ void k_dft_rows(const double *__restrict__ srcD, const float *__restrict__ srcF,
-                           const double *__restrict__ tempden, float NormDen, int N, int H,
+                           const double *__restrict__ tempden, float NormDen, int N, int H, int A, int B,
                            const double2 *__restrict__ twD, double2 *__restrict__ rowspec)
 {
-  extern __shared__ double srow[];
+  extern __shared__ double srow[];          // N doubles, then N double2
+  double2 *Y = reinterpret_cast<double2 *>(srow + N + (N & 1));
   const int i = blockIdx.x, b = blockIdx.y;
   float ratio = 1.f;
   if (srcD)
@@ -299,15 +316,38 @@ __global__ void k_dft_rows(const double *__restrict__ srcD, const float *__restr
     srow[j] = (double) v;
   }
   __syncthreads();
-  for (int k = threadIdx.x; k < H; k += blockDim.x)
+  for (int e = threadIdx.x; e < N; e += blockDim.x)
   {
+    const int j1 = e / B, kb = e - j1 * B;
     double ar = 0., ai = 0.;
     int idx = 0;
-    for (int j = 0; j < N; j++)
+    const int step = (A * kb) % N;
+    for (int j2 = 0; j2 < B; j2++)
     {
       const double2 w = twD[idx];
-      ar = fma(srow[j], w.x, ar);
-      ai = fma(-srow[j], w.y, ai); // forward: e^{-i}
+      const double x = srow[A * j2 + j1];
+      ar = fma(x, w.x, ar);
+      ai = fma(-x, w.y, ai); // forward: e^{-i}
+      idx += step;
+      if (idx >= N)
+        idx -= N;
+    }
+    Y[e] = make_double2(ar, ai);
+  }
+  __syncthreads();
+  for (int k = threadIdx.x; k < H; k += blockDim.x)
+  {
+    const int kb = k % B;
+    double ar = 0., ai = 0.;
+    int idx = 0;
+    for (int j1 = 0; j1 < A; j1++)
+    {
+      const double2 w = twD[idx]; // multiply by conj(w)
+      const double2 y = Y[j1 * B + kb];
+      ar = fma(y.x, w.x, ar);
+      ar = fma(y.y, w.y, ar);
+      ai = fma(y.y, w.x, ai);
+      ai = fma(-y.x, w.y, ai);
       idx += k;
       if (idx >= N)
         idx -= N;
@@ -316,26 +356,50 @@ __global__ void k_dft_rows(const double *__restrict__ srcD, const float *__restr
   }
 }
 
-__global__ void k_dft_cols(const double2 *__restrict__ rowspec, int N, int H, const double2 *__restrict__ twD,
-                           float2 *__restrict__ out)
+__global__ void k_dft_cols(const double2 *__restrict__ rowspec, int N, int H, int A, int B,
+                           const double2 *__restrict__ twD, float2 *__restrict__ out)
 {
   extern __shared__ double srow[];
-  double2 *col = (double2 *) srow;
+  double2 *col = reinterpret_cast<double2 *>(srow);
+  double2 *Y = col + N;
   const int k = blockIdx.x, b = blockIdx.y;
   for (int i = threadIdx.x; i < N; i += blockDim.x)
     col[i] = rowspec[((size_t) b * N + i) * H + k];
   __syncthreads();
-  for (int u = threadIdx.x; u < N; u += blockDim.x)
+  for (int e = threadIdx.x; e < N; e += blockDim.x)
   {
+    const int j1 = e / B, kb = e - j1 * B;
     double ar = 0., ai = 0.;
     int idx = 0;
-    for (int i = 0; i < N; i++)
+    const int step = (A * kb) % N;
+    for (int j2 = 0; j2 < B; j2++)
     {
-      const double2 w = twD[idx]; // multiply by conj(w)
-      ar = fma(col[i].x, w.x, ar);
-      ar = fma(col[i].y, w.y, ar);
-      ai = fma(col[i].y, w.x, ai);
-      ai = fma(-col[i].x, w.y, ai);
+      const double2 w = twD[idx];
+      const double2 x = col[A * j2 + j1];
+      ar = fma(x.x, w.x, ar);
+      ar = fma(x.y, w.y, ar);
+      ai = fma(x.y, w.x, ai);
+      ai = fma(-x.x, w.y, ai);
+      idx += step;
+      if (idx >= N)
+        idx -= N;
+    }
+    Y[e] = make_double2(ar, ai);
+  }
+  __syncthreads();
+  for (int u = threadIdx.x; u < N; u += blockDim.x)
+  {
+    const int kb = u % B;
+    double ar = 0., ai = 0.;
+    int idx = 0;
+    for (int j1 = 0; j1 < A; j1++)
+    {
+      const double2 w = twD[idx];
+      const double2 y = Y[j1 * B + kb];
+      ar = fma(y.x, w.x, ar);
+      ar = fma(y.y, w.y, ar);
+      ai = fma(y.y, w.x, ai);
+      ai = fma(-y.x, w.y, ai);
       idx += u;
       if (idx >= N)
         idx -= N;
@@ -1117,6 +1181,77 @@ __global__ void k_fold(const Partial *__restrict__ partials, int ldPart, int nOC
 }
 
 // ------------------------------------------------------------------------------------------------
+// wave-parallel fold (no WRITE_PROB_ANGLES): one wave per particle; lane l folds a contiguous chunk of
+// (orientation, CTF) partials in order, the 64 chunk results are merged by a shuffle reduction that keeps
+// the FIRST maximum (lowest index), then combined with the running state exactly like the sequential fold.
+// The log-sum-exp merge is associative, so the result equals k_fold's up to double rounding (1e-16).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_fold_wave(const Partial *__restrict__ partials, int ldPart, int nOC,
+                                                   int nMaps, const bioem_hip_param5 *__restrict__ params,
+                                                   const float *__restrict__ sumRef, const int *__restrict__ disp,
+                                                   int nd, PD pd, int orient0, int conv0, int convPerOrient,
+                                                   bioem_hip_prob_map *__restrict__ pmap)
+{
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int p = blockIdx.x * 4 + wave;
+  if (p >= nMaps)
+    return;
+  const Partial *P = partials + (size_t) p * ldPart;
+  const int chunk = (nOC + 63) / 64;
+  const int b = lane * chunk, e = min(nOC, b + chunk);
+  double m = -INFINITY, sacc = 0.;
+  int idx = 0x7fffffff;
+  for (int oc = b; oc < e; oc++)
+  {
+    const Partial r = P[oc];
+    const double lp = (double) r.best;
+    if (m < lp)
+    {
+      sacc = (m == -INFINITY) ? 0. : sacc * exp(m - lp);
+      m = lp;
+      idx = oc;
+    }
+    sacc += r.sumExp * exp(lp - m);
+  }
+  for (int off = 32; off > 0; off >>= 1)
+  {
+    const double m2 = __shfl_xor(m, off);
+    const double s2 = __shfl_xor(sacc, off);
+    const int i2 = __shfl_xor(idx, off);
+    if (m2 > m || (m2 == m && i2 < idx))
+    {
+      sacc = ((m == -INFINITY) ? 0. : sacc * exp(m - m2)) + s2;
+      m = m2;
+      idx = i2;
+    }
+    else
+      sacc += (m2 == -INFINITY) ? 0. : s2 * exp(m2 - m);
+  }
+  if (lane == 0 && idx != 0x7fffffff)
+  {
+    bioem_hip_prob_map pm = pmap[p];
+    if (pm.Constoadd < m)
+    {
+      pm.Total *= exp(-m + pm.Constoadd);
+      pm.Constoadd = m;
+      const Partial r = P[idx];
+      const int ix = r.id / nd, iy = r.id - ix * nd;
+      pm.max_prob_cent_x = -disp[ix];
+      pm.max_prob_cent_y = -disp[iy];
+      pm.max_prob_orient = orient0 + idx / convPerOrient;
+      pm.max_prob_conv = conv0 + idx % convPerOrient;
+      const bioem_hip_param5 q = params[idx];
+      const float sumref = sumRef[p];
+      const float value = r.value;
+      pm.max_prob_norm = -(-q.sumC * sumref + pd.Ntotpi * value) / (q.sumC * q.sumC - q.sumsquareC * pd.Ntotpi);
+      pm.max_prob_mu = -(-q.sumC * value + q.sumsquareC * sumref) / (q.sumC * q.sumC - q.sumsquareC * pd.Ntotpi);
+    }
+    pm.Total += sacc * exp(m - pm.Constoadd);
+    pmap[p] = pm;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // host helpers
 // ------------------------------------------------------------------------------------------------
 size_t compare_lds_bytes(int N, int H, int NW, int waves)
@@ -1157,12 +1292,33 @@ void drain_events(bioem_hip_ctx *h)
   h->evPending.clear();
 }
 
-int launch_compare_fold(bioem_hip_ctx *h, int nOC, int orient0, int conv0, int convPerOrient)
+struct BatchBuf
+{
+  double *projReal;
+  double *tempDen;
+  double2 *rowSpec;
+  float2 *specRef;
+  float *scratch;
+  float2 *conv;
+  bioem_hip_param5 *params;
+};
+
+BatchBuf batch_buf(bioem_hip_ctx *h, int which)
+{
+  BatchBuf b;
+  if (which == 0)
+    b = {h->dProjReal, h->dTempDen, h->dRowSpec, h->dSpecRef, h->dScratch, h->dConv, h->dParams};
+  else
+    b = {h->dProjReal2, h->dTempDen2, h->dRowSpec2, h->dSpecRef2, h->dScratch2, h->dConv2, h->dParams2};
+  return b;
+}
+
+int launch_compare_fold(bioem_hip_ctx *h, const BatchBuf &bb, int nOC, int orient0, int conv0, int convPerOrient)
 {
   CompareArgs a;
   a.ref = h->dRef;
-  a.conv = h->dConv;
-  a.params = h->dParams;
+  a.conv = bb.conv;
+  a.params = bb.params;
   a.sumRef = h->dSumRef;
   a.sumsqRef = h->dSumsqRef;
   a.tw = h->dTw;
@@ -1210,43 +1366,58 @@ int launch_compare_fold(bioem_hip_ctx *h, int nOC, int orient0, int conv0, int c
   h->comparisons += (long long) nOC * h->nMaps;
   bioem_hip_prob_map *pmap = reinterpret_cast<bioem_hip_prob_map *>(h->dProb);
   bioem_hip_prob_angle *pang = reinterpret_cast<bioem_hip_prob_angle *>(h->dProb + sizeof(bioem_hip_prob_map) * h->nMaps);
-  hipLaunchKernelGGL(k_fold, dim3((h->nMaps + 127) / 128), dim3(128), 0, h->stream, h->dPartials, h->maxOC, nOC,
-                     h->nMaps, h->dParams, h->dSumRef, h->dDisp, h->nd, h->pd, orient0, conv0, convPerOrient, pmap,
-                     pang);
+  if (h->pd.writeAngles)
+    hipLaunchKernelGGL(k_fold, dim3((h->nMaps + 127) / 128), dim3(128), 0, h->stream, h->dPartials, h->maxOC, nOC,
+                       h->nMaps, bb.params, h->dSumRef, h->dDisp, h->nd, h->pd, orient0, conv0, convPerOrient, pmap,
+                       pang);
+  else
+    hipLaunchKernelGGL(k_fold_wave, dim3((h->nMaps + 3) / 4), dim3(256), 0, h->stream, h->dPartials, h->maxOC, nOC,
+                       h->nMaps, bb.params, h->dSumRef, h->dDisp, h->nd, h->pd, orient0, conv0, convPerOrient, pmap);
   HIP_CHECK(h, hipGetLastError());
   if (h->evPending.size() > 512)
     drain_events(h);
   return 0;
 }
 
-// r2c of nImg images (either double projection maps with tempden scaling, or float maps) into dSpecRef
-int run_r2c(bioem_hip_ctx *h, const double *srcD, const float *srcF, int nImg)
+void dft_split(int N, int &A, int &B)
+{
+  A = 1;
+  for (int d = 1; d * d <= N; d++)
+    if (N % d == 0)
+      A = d;
+  B = N / A;
+}
+
+// r2c of nImg images (either double projection maps with tempden scaling, or float maps) into bb.specRef
+int run_r2c(bioem_hip_ctx *h, const BatchBuf &bb, hipStream_t st, const double *srcD, const float *srcF, int nImg)
 {
   const int N = h->N, H = h->H;
-  hipLaunchKernelGGL(k_dft_rows, dim3(N, nImg), dim3(128), sizeof(double) * N, h->stream, srcD, srcF, h->dTempDen,
-                     h->NormDen, N, H, h->dTwD, h->dRowSpec);
+  int A, B;
+  dft_split(N, A, B);
+  hipLaunchKernelGGL(k_dft_rows, dim3(N, nImg), dim3(128), sizeof(double) * (3 * N + 2), st, srcD, srcF, bb.tempDen,
+                     h->NormDen, N, H, A, B, h->dTwD, bb.rowSpec);
   HIP_CHECK(h, hipGetLastError());
-  hipLaunchKernelGGL(k_dft_cols, dim3(H, nImg), dim3(256), sizeof(double2) * N, h->stream, h->dRowSpec, N, H, h->dTwD,
-                     h->dSpecRef);
+  hipLaunchKernelGGL(k_dft_cols, dim3(H, nImg), dim3(256), sizeof(double2) * 2 * N, st, bb.rowSpec, N, H, A, B,
+                     h->dTwD, bb.specRef);
   HIP_CHECK(h, hipGetLastError());
   return 0;
 }
 
-int project_batch(bioem_hip_ctx *h, int o0, int nO)
+int project_batch(bioem_hip_ctx *h, const BatchBuf &bb, hipStream_t st, int o0, int nO)
 {
   const int N = h->N;
-  HIP_CHECK(h, hipMemsetAsync(h->dProjReal, 0, sizeof(double) * (size_t) nO * N * N, h->stream));
-  HIP_CHECK(h, hipMemsetAsync(h->dTempDen, 0, sizeof(double) * nO, h->stream));
-  hipLaunchKernelGGL(k_project, dim3((h->nPts + 255) / 256, nO), dim3(256), 0, h->stream, h->dPts, h->nPts,
-                     h->dAngles, o0, h->isQuat, N, h->pixelSize, h->shiftX, h->shiftY, h->dProjReal, h->dTempDen);
+  HIP_CHECK(h, hipMemsetAsync(bb.projReal, 0, sizeof(double) * (size_t) nO * N * N, st));
+  HIP_CHECK(h, hipMemsetAsync(bb.tempDen, 0, sizeof(double) * nO, st));
+  hipLaunchKernelGGL(k_project, dim3((h->nPts + 255) / 256, nO), dim3(256), 0, st, h->dPts, h->nPts, h->dAngles, o0,
+                     h->isQuat, N, h->pixelSize, h->shiftX, h->shiftY, bb.projReal, bb.tempDen);
   HIP_CHECK(h, hipGetLastError());
-  return run_r2c(h, h->dProjReal, nullptr, nO);
+  return run_r2c(h, bb, st, bb.projReal, nullptr, nO);
 }
 
-int convolve_batch(bioem_hip_ctx *h, int nO)
+int convolve_batch(bioem_hip_ctx *h, const BatchBuf &bb, hipStream_t st, int nO)
 {
-  hipLaunchKernelGGL(k_convolve, dim3(h->nCTF, nO), dim3(256), 0, h->stream, h->dSpecRef, h->dCTF, h->dCtfParam, h->N,
-                     h->H, h->fast, h->N1, h->nCTF, h->dConv, h->dScratch, h->dParams);
+  hipLaunchKernelGGL(k_convolve, dim3(h->nCTF, nO), dim3(256), 0, st, bb.specRef, h->dCTF, h->dCtfParam, h->N, h->H,
+                     h->fast, h->N1, h->nCTF, bb.conv, bb.scratch, bb.params);
   HIP_CHECK(h, hipGetLastError());
   return 0;
 }
@@ -1300,7 +1471,11 @@ int bioem_hip_create(bioem_hip_handle *out, int device, const bioem_hip_param_de
     return 2;
   }
   HIP_CHECK(h, hipSetDevice(device));
-  HIP_CHECK(h, hipStreamCreate(&h->stream));
+  {
+    int prLow = 0, prHigh = 0;
+    HIP_CHECK(h, hipDeviceGetStreamPriorityRange(&prLow, &prHigh));
+    HIP_CHECK(h, hipStreamCreateWithPriority(&h->stream, hipStreamNonBlocking, prHigh));
+  }
 
   // displacement list per axis in the reference's visiting order
   const int maxD = pd->maxDisplaceCenter, g = pd->GridSpaceCenter;
@@ -1386,6 +1561,24 @@ int bioem_hip_create(bioem_hip_handle *out, int device, const bioem_hip_param_de
   HIP_CHECK(h, hipMalloc(&h->dPartials, sizeof(Partial) * (size_t) nMaps * h->maxOC));
   h->probBytes = bioem_hip_prob_size(nMaps, nAngles, pd->writeAngles);
   HIP_CHECK(h, hipMalloc(&h->dProb, h->probBytes));
+  {
+    // projection/convolution are filler work: lowest priority so that comparison blocks win the CUs
+    int prLow = 0, prHigh = 0;
+    HIP_CHECK(h, hipDeviceGetStreamPriorityRange(&prLow, &prHigh));
+    HIP_CHECK(h, hipStreamCreateWithPriority(&h->prepStream, hipStreamNonBlocking, prLow));
+  }
+  HIP_CHECK(h, hipMalloc(&h->dProjReal2, sizeof(double) * (size_t) h->OB * N * N));
+  HIP_CHECK(h, hipMalloc(&h->dTempDen2, sizeof(double) * h->OB));
+  HIP_CHECK(h, hipMalloc(&h->dRowSpec2, sizeof(double2) * (size_t) h->OB * M));
+  HIP_CHECK(h, hipMalloc(&h->dSpecRef2, sizeof(float2) * (size_t) h->OB * M));
+  HIP_CHECK(h, hipMalloc(&h->dScratch2, sizeof(float) * (size_t) h->maxOC * M));
+  HIP_CHECK(h, hipMalloc(&h->dConv2, sizeof(float2) * (size_t) h->maxOC * M));
+  HIP_CHECK(h, hipMalloc(&h->dParams2, sizeof(bioem_hip_param5) * h->maxOC));
+  for (int i = 0; i < 2; i++)
+  {
+    HIP_CHECK(h, hipEventCreateWithFlags(&h->prepDone[i], hipEventDisableTiming));
+    HIP_CHECK(h, hipEventCreateWithFlags(&h->cmpDone[i], hipEventDisableTiming));
+  }
 
   std::vector<float2> tw(N + 1);
   std::vector<double2> twd(N);
@@ -1439,7 +1632,8 @@ int bioem_hip_destroy(bioem_hip_handle h)
     hipEventDestroy(e);
   void *ptrs[] = {h->dRef,     h->dSumRef,  h->dSumsqRef, h->dCTF,     h->dCtfParam, h->dPts,   h->dAngles,
                   h->dTw,      h->dTwD,     h->dDisp,     h->dLtab,    h->dTwk,     h->dProjReal, h->dTempDen,  h->dRowSpec, h->dSpecRef,
-                  h->dScratch, h->dConv,    h->dParams,   h->dPartials, h->dProb,     h->dStage};
+                  h->dScratch, h->dConv,    h->dParams,   h->dPartials, h->dProb,     h->dStage,
+                  h->dProjReal2, h->dTempDen2, h->dRowSpec2, h->dSpecRef2, h->dScratch2, h->dConv2, h->dParams2};
   for (void *p : ptrs)
     if (p)
       hipFree(p);
@@ -1448,8 +1642,19 @@ int bioem_hip_destroy(bioem_hip_handle h)
   if (h->hStageP)
     hipHostFree(h->hStageP);
   for (int i = 0; i < 2; i++)
+  {
     if (h->slotEvent[i])
       hipEventDestroy(h->slotEvent[i]);
+    if (h->prepDone[i])
+      hipEventDestroy(h->prepDone[i]);
+    if (h->cmpDone[i])
+      hipEventDestroy(h->cmpDone[i]);
+  }
+  if (h->prepStream)
+  {
+    hipStreamSynchronize(h->prepStream);
+    hipStreamDestroy(h->prepStream);
+  }
   if (h->stream)
     hipStreamDestroy(h->stream);
   delete h;
@@ -1489,7 +1694,7 @@ int bioem_hip_upload_particle_maps(bioem_hip_handle h, const float *maps)
                                 hipMemcpyHostToDevice, h->stream));
     hipLaunchKernelGGL(k_map_sums, dim3(n), dim3(256), 0, h->stream, dMaps, N * N, h->dSumRef + b, h->dSumsqRef + b);
     HIP_CHECK(h, hipGetLastError());
-    if (run_r2c(h, nullptr, dMaps, n))
+    if (run_r2c(h, batch_buf(h, 0), h->stream, nullptr, dMaps, n))
     {
       hipFree(dMaps);
       return 1;
@@ -1604,7 +1809,7 @@ int bioem_hip_compare(bioem_hip_handle h, int iPipeline, int iOrient, int iConvS
   hipLaunchKernelGGL(k_reorder, dim3(256), dim3(256), 0, h->stream, h->dStage, h->dConv, maxParallelConv, h->N, h->H,
                      h->fast, h->N1);
   HIP_CHECK(h, hipGetLastError());
-  if (launch_compare_fold(h, maxParallelConv, iOrient, iConvStart, maxParallelConv))
+  if (launch_compare_fold(h, batch_buf(h, 0), maxParallelConv, iOrient, iConvStart, maxParallelConv))
     return 1;
   HIP_CHECK(h, hipEventRecord(h->slotEvent[par], h->stream));
   h->slotPending[par] = true;
@@ -1619,16 +1824,45 @@ int bioem_hip_project_convolve_compare(bioem_hip_handle h, int iOrientBegin, int
     h->err = "project_convolve_compare: model/orientations not uploaded or range invalid";
     return 2;
   }
-  for (int o0 = iOrientBegin; o0 < iOrientEnd; o0 += h->OB)
-  {
+  // two-slot pipeline: projection + convolution of batch b+1 run on prepStream while batch b is compared
+  const int nb = (iOrientEnd - iOrientBegin + h->OB - 1) / h->OB;
+  auto prep = [&](int b) -> int {
+    const int slot = b & 1;
+    const int o0 = iOrientBegin + b * h->OB;
     const int nO = std::min(h->OB, iOrientEnd - o0);
-    if (project_batch(h, o0, nO))
+    const BatchBuf bb = batch_buf(h, slot);
+    if (h->cmpPending[slot])
+    {
+      HIP_CHECK(h, hipStreamWaitEvent(h->prepStream, h->cmpDone[slot], 0));
+      h->cmpPending[slot] = false;
+    }
+    if (project_batch(h, bb, h->prepStream, o0, nO))
       return 1;
-    if (convolve_batch(h, nO))
+    if (convolve_batch(h, bb, h->prepStream, nO))
       return 1;
-    if (launch_compare_fold(h, nO * h->nCTF, o0, 0, h->nCTF))
+    HIP_CHECK(h, hipEventRecord(h->prepDone[slot], h->prepStream));
+    return 0;
+  };
+  // anything still queued on the main stream that uses slot 0/1 buffers (debug hooks, compat entry) goes first
+  HIP_CHECK(h, hipEventRecord(h->cmpDone[0], h->stream));
+  HIP_CHECK(h, hipEventRecord(h->cmpDone[1], h->stream));
+  h->cmpPending[0] = h->cmpPending[1] = true;
+  if (nb > 0 && prep(0))
+    return 1;
+  for (int b = 0; b < nb; b++)
+  {
+    const int slot = b & 1;
+    const int o0 = iOrientBegin + b * h->OB;
+    const int nO = std::min(h->OB, iOrientEnd - o0);
+    if (b + 1 < nb && prep(b + 1))
       return 1;
+    HIP_CHECK(h, hipStreamWaitEvent(h->stream, h->prepDone[slot], 0));
+    if (launch_compare_fold(h, batch_buf(h, slot), nO * h->nCTF, o0, 0, h->nCTF))
+      return 1;
+    HIP_CHECK(h, hipEventRecord(h->cmpDone[slot], h->stream));
+    h->cmpPending[slot] = true;
   }
+  // later main-stream work (finish_run, debug hooks) must also see prepStream drained: it is, through prepDone
   return 0;
 }
 
@@ -1708,7 +1942,7 @@ int bioem_hip_merge_host(int nShards, int nMaps, int nAngles, int writeAngles, c
 int bioem_hip_debug_projection(bioem_hip_handle h, int iOrient, float *spec_out)
 {
   HIP_CHECK(h, hipSetDevice(h->device));
-  if (project_batch(h, iOrient, 1))
+  if (project_batch(h, batch_buf(h, 0), h->stream, iOrient, 1))
     return 1;
   HIP_CHECK(h, hipMemcpyAsync(spec_out, h->dSpecRef, sizeof(float2) * (size_t) h->M, hipMemcpyDeviceToHost, h->stream));
   HIP_CHECK(h, hipStreamSynchronize(h->stream));
@@ -1719,9 +1953,9 @@ int bioem_hip_debug_convolution(bioem_hip_handle h, int iOrient, int iConv, floa
                                 float *sumsquareC)
 {
   HIP_CHECK(h, hipSetDevice(h->device));
-  if (project_batch(h, iOrient, 1))
+  if (project_batch(h, batch_buf(h, 0), h->stream, iOrient, 1))
     return 1;
-  if (convolve_batch(h, 1))
+  if (convolve_batch(h, batch_buf(h, 0), h->stream, 1))
     return 1;
   const size_t M = (size_t) h->M;
   float2 *tmp = h->dSpecRef + M; // chunkB >= 32 slots; slot 0 holds the projection spectrum
@@ -1805,9 +2039,11 @@ int bioem_hip_r2c(int device, int N, int nImg, const float *in, float *out)
       hipMemcpy(dTw, twd.data(), sizeof(double2) * N, hipMemcpyHostToDevice) == hipSuccess &&
       hipMemcpy(dIn, in, sizeof(float) * (size_t) N * N * nImg, hipMemcpyHostToDevice) == hipSuccess)
   {
-    hipLaunchKernelGGL(k_dft_rows, dim3(N, nImg), dim3(128), sizeof(double) * N, 0, nullptr, dIn, nullptr, 1.f, N, H,
-                       dTw, dRow);
-    hipLaunchKernelGGL(k_dft_cols, dim3(H, nImg), dim3(256), sizeof(double2) * N, 0, dRow, N, H, dTw, dOut);
+    int A, B;
+    dft_split(N, A, B);
+    hipLaunchKernelGGL(k_dft_rows, dim3(N, nImg), dim3(128), sizeof(double) * (3 * N + 2), 0, nullptr, dIn, nullptr,
+                       1.f, N, H, A, B, dTw, dRow);
+    hipLaunchKernelGGL(k_dft_cols, dim3(H, nImg), dim3(256), sizeof(double2) * 2 * N, 0, dRow, N, H, A, B, dTw, dOut);
     if (hipGetLastError() == hipSuccess &&
         hipMemcpy(out, dOut, sizeof(float2) * M * nImg, hipMemcpyDeviceToHost) == hipSuccess)
       rc = 0;
