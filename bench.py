@@ -77,18 +77,26 @@ def main():
     if not torch.cuda.is_available():
         print("bench.py needs a GPU: the engine has no CPU path", file=sys.stderr)
         sys.exit(2)
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # rehearsal knobs (not used by the driver): BIOEM_BENCH_BACKEND=gloo runs the N>1 control flow with every
+    # rank on ONE GPU (merge tensors on the CPU) -- RCCL itself refuses two ranks on the same device.
+    backend = os.environ.get("BIOEM_BENCH_BACKEND", "nccl")
+    gpu_index = local_rank if backend == "nccl" else int(os.environ.get("BIOEM_BENCH_DEVICE", "0"))
+    torch.cuda.set_device(gpu_index)
+    dev = torch.device("cuda", gpu_index) if backend == "nccl" else torch.device("cpu")
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
+    from bioem_amd.dist_merge import merge_prob_maps
     from bioem_amd.engine import new_prob_block
     from bioem_amd.synthetic import Workload
 
     # every rank renders the same particle stack (same seeds); orientation seed differs per rank so that the
     # global list is the concatenation of `world` distinct blocks of `orientations` each.
-    W = Workload(N=args.pixels, nP=args.particles, nOrient=args.orientations, device=local_rank,
+    W = Workload(N=args.pixels, nP=args.particles, nOrient=args.orientations, device=gpu_index,
                  orient_seed=20260103 + rank)
     E = W.engine
     nMaps = W.nP
@@ -99,18 +107,8 @@ def main():
         E.project_convolve_compare(0, W.nOrient)
         E.finish_run(raw)
         if world > 1:
-            # log-sum-exp merge of bioem.cpp:909-994 over RCCL: C* = max C_s; Total* = sum Total_s exp(C_s - C*)
-            const = torch.from_numpy(pmap["Constoadd"].copy()).to(dev)
-            total = torch.from_numpy(pmap["Total"].copy()).to(dev)
-            cmax = const.clone()
-            dist.all_reduce(cmax, op=dist.ReduceOp.MAX)
-            total = total * torch.exp(const - cmax)
-            dist.all_reduce(total, op=dist.ReduceOp.SUM)
-            # owner of the arg-max: lowest rank holding C* (lowest orientation block)
-            owner = torch.where(const >= cmax, torch.full_like(const, float(rank)), torch.full_like(const, 1e9))
-            dist.all_reduce(owner, op=dist.ReduceOp.MIN)
-            torch.cuda.synchronize()
-            return total, cmax, owner
+            # the path's single exchange step: log-sum-exp merge of bioem.cpp:909-994 over RCCL
+            return merge_prob_maps(pmap, dev)
         return pmap
 
     def sync():

@@ -352,3 +352,85 @@ def test_full_size_slice_against_oracle(full_workload):
         assert abs(la - lb) <= REL_TOL * abs(lb) and abs(la - lb) <= ABS_TOL
         assert (got[p]["orient"], got[p]["conv"], got[p]["cent_x"], got[p]["cent_y"]) == \
                (want[i]["orient"], want[i]["conv"], want[i]["cent_x"], want[i]["cent_y"])
+
+
+def _write_mrc(path, data):
+    import struct
+    ns, nr, nc = data.shape
+    hdr = np.zeros(256, dtype="<i4")
+    hdr[0:4] = [nc, nr, ns, 2]
+    hdr[7:10] = [nc, nr, ns]
+    raw = hdr.tobytes()
+    raw = raw[:40] + struct.pack("<6f", 100., 100., 100., 90., 90., 90.) + raw[64:]
+    with open(path, "wb") as f:
+        f.write(raw + data.astype("<f4").tobytes())
+
+
+def test_config5_shape_mrc_input_256_write_prob_angles(tmp_path):
+    """BASELINE config 5 shape at small counts: 256^2 particles read from MRC stacks (--ReadMRC --ReadMultipleMRC),
+    WRITE_PROB_ANGLES on, through the drop-in CLI; oracle fed with the images exactly as the reader delivers them."""
+    from bioem_amd import hostlib
+    N, nP = 256, 4
+    case, _ = setup_for("g2_n128")
+    rng = np.random.default_rng(11)
+    up = np.kron(case["maps"][:nP], np.ones((2, 2), dtype=np.float32))          # 128 -> 256
+    stack = (3.0 * up + rng.normal(size=up.shape) + 7.0).astype(np.float32)     # un-normalised raw counts
+    d = tmp_path
+    _write_mrc(str(d / "a.mrc"), stack[:2])
+    _write_mrc(str(d / "b.mrc"), stack[2:])
+    with open(d / "list.txt", "w") as f:
+        f.write(str(d / "a.mrc") + "\n" + str(d / "b.mrc") + "\n")
+    iof.write_text_model(str(d / "model.txt"), case["model"])
+    kw = [("PIXEL_SIZE", [1.0]), ("NUMBER_PIXELS", [N]), ("USE_QUATERNIONS", []), ("CTF_B_ENV", [2.0, 300.0, 2]),
+          ("CTF_DEFOCUS", [1.0, 4.0, 2]), ("CTF_AMPLITUDE", [0.1, 0.1, 1]), ("DISPLACE_CENTER", [10, 1]),
+          ("WRITE_PROB_ANGLES", [3])]
+    iof.write_param_file(str(d / "param.txt"), kw)
+    lines = case["orient_lines"][:9]
+    with open(d / "orient.txt", "w") as f:
+        f.write("%d\n" % len(lines) + "\n".join(lines) + "\n")
+    exe = os.path.join(ROOT, "bioem_amd", "bin", "bioEM")
+    r = subprocess.run([exe, "--Modelfile", "model.txt", "--Particlesfile", "list.txt", "--Inputfile", "param.txt",
+                        "--ReadOrientation", "orient.txt", "--ReadMRC", "--ReadMultipleMRC"], cwd=str(d),
+                       env=dict(os.environ, BIOEM_GPUS="1"), stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                       text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:]
+    maps = hostlib.read_particles(str(d / "list.txt"), N, mode=2)
+    assert maps.shape == (nP, N, N)
+    S = orc.Setup(orc.parse_param_file(str(d / "param.txt")), case["model"], maps, lines)
+    want, wang = S.run(1)
+    mine = iof.parse_output_probabilities(open(d / "Output_Probabilities").read())
+    ref = iof.parse_output_probabilities(orc.format_output_probabilities(S, want))
+    for g, m in zip(ref, mine):
+        assert abs(g["logp"] - m["logp"]) <= max(ABS_TOL, REL_TOL * abs(g["logp"]))
+        assert (g["angles"], g["ctf"], g["cx"], g["cy"]) == (m["angles"], m["ctf"], m["cx"], m["cy"])
+    rows = orc.ang_prob_rows(S, want, wang)
+    ma = iof.parse_ang_prob(str(d / "ANG_PROB"))
+    for m_ in rows:
+        assert len(ma[m_]) == 3
+        for g, m in zip(rows[m_], ma[m_]):
+            assert m["angles"] == [float("%.4f" % v) for v in S.angles[g["orient"]]]
+            assert abs(g["logp"] - m["logp"]) <= 5e-3
+
+
+def test_config3_shape_ten_ctfs_two_shards():
+    """BASELINE config 3 shape at small counts: 224^2, 2 defocus x 5 envelope = 10 CTFs, two orientation shards
+    with private probability blocks merged by the log-sum-exp rule, against the oracle's unsharded run."""
+    import bioem_amd.engine as eng
+    case, _ = setup_for("g7_n224")
+    P = dict(case["P"])
+    f32 = np.float32
+    import math
+    fac = math.pi * 2.0 * 10000 * float(P["elecwavel"])
+    P["nPhase"], P["startPhase"], P["endPhase"] = 2, f32(1.0 * fac), f32(4.0 * fac)
+    P["nEnv"], P["startEnv"], P["endEnv"] = 5, f32(2.0), f32(300.0)
+    S = orc.Setup(P, case["model"], case["maps"], case["orient_lines"])
+    assert S.nCTF == 10
+    E = make_engine(S, 1)
+    blocks = []
+    for g in range(2):
+        raw, _, _ = run_native(E, S, g * S.nAngles // 2, (g + 1) * S.nAngles // 2)
+        blocks.append(raw.copy())
+    merged = eng.merge_host(blocks, S.nMaps, S.nAngles, 0).view(eng.PROB_MAP_DTYPE)
+    want, _ = S.run(1)
+    assert_same_posterior(S, merged, want)
+    E.close()
