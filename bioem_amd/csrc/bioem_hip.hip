@@ -699,6 +699,54 @@ __device__ __forceinline__ float4 as_float4(u32x4 v)
   return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
 }
 
+// 32-point inverse FFT, radix-2 decimation in time: input must be stored at the bit-reversed position
+// (element k2 at index bitrev5(k2)), output in natural order.  Twiddled butterflies use
+//   out0 = a + w*b  (4 FMAs),  out1 = 2a - out0  (2 FMAs)
+// i.e. 6 instead of 8 operations.
+__device__ __forceinline__ void fft32_inverse_dit(float (&xr)[32], float (&xi)[32])
+{
+#pragma unroll
+  for (int s = 0; s < 5; s++)
+  {
+    const int m = 1 << s;
+#pragma unroll
+    for (int b = 0; b < 32; b += 2 * m)
+    {
+#pragma unroll
+      for (int j = 0; j < m; j++)
+      {
+        const int i0 = b + j, i1 = b + j + m;
+        const int t = j * (16 >> s); // w_32^t = exp(+2 pi i j / (2m))
+        const float ar = xr[i0], ai = xi[i0], br = xr[i1], bi = xi[i1];
+        if (t == 0)
+        {
+          xr[i0] = ar + br;
+          xi[i0] = ai + bi;
+          xr[i1] = ar - br;
+          xi[i1] = ai - bi;
+        }
+        else if (t == 8)
+        { // w = i: w*b = (-bi, br)
+          xr[i0] = ar - bi;
+          xi[i0] = ai + br;
+          xr[i1] = ar + bi;
+          xi[i1] = ai - br;
+        }
+        else
+        {
+          const float c = COS32[t], sn = SIN32[t];
+          const float o0r = fmaf(-sn, bi, fmaf(c, br, ar));
+          const float o0i = fmaf(sn, br, fmaf(c, bi, ai));
+          xr[i0] = o0r;
+          xi[i0] = o0i;
+          xr[i1] = fmaf(2.0f, ar, -o0r);
+          xi[i1] = fmaf(2.0f, ai, -o0i);
+        }
+      }
+    }
+  }
+}
+
 struct CompareArgs
 {
   const float2 *ref;  // [nMaps][M] comparison layout
@@ -836,11 +884,38 @@ __device__ __forceinline__ void window_accumulate(const float2 *Tl, const float2
 // FFTs -> T block in LDS -> window accumulation, so the LDS footprint per wave is (2*WD+1)*64*8 bytes
 // (10.5 KiB for +-10 px => 3 blocks per CU, matching the VGPR-limited 3 waves per SIMD).
 // ------------------------------------------------------------------------------------------------
+// FFT flavour: decimation in time with 6-op butterflies (default) or the decimation-in-frequency original
+#ifndef BIOEM_FFT_DIF
+#define BIOEM_FFT_DIF 0
+#endif
+#if BIOEM_FFT_DIF
+#define FFT_IN(k) (k)
+#define FFT_OUT(n) bitrev5(n)
+#define FFT_RUN(xr, xi) fft32_inverse(xr, xi)
+#else
+#define FFT_IN(k) bitrev5(k)
+#define FFT_OUT(n) (n)
+#define FFT_RUN(xr, xi) fft32_inverse_dit(xr, xi)
+#endif
+#ifndef BIOEM_BLOCK_BARRIER
+#define BIOEM_BLOCK_BARRIER 1
+#endif
+#if BIOEM_BLOCK_BARRIER
+#define WAVE_OR_BLOCK_SYNC() __syncthreads()
+#else
+#define WAVE_OR_BLOCK_SYNC()                                                                                       \
+  do                                                                                                               \
+  {                                                                                                                \
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");                                                         \
+    __builtin_amdgcn_wave_barrier();                                                                               \
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");                                                         \
+  } while (0)
+#endif
 #ifndef BIOEM_FAST_WAVES_PER_SIMD
 #define BIOEM_FAST_WAVES_PER_SIMD 3
 #endif
 template <int WD>
-__global__ __launch_bounds__(256, BIOEM_FAST_WAVES_PER_SIMD) void k_compare_fast(const CompareArgs a)
+__global__ __launch_bounds__(256, (WD <= 10 ? BIOEM_FAST_WAVES_PER_SIMD : 2)) void k_compare_fast(const CompareArgs a)
 {
   constexpr int NW = 2 * WD + 1;
   constexpr int NR = (WD <= 10) ? 7 : 16;
@@ -871,10 +946,18 @@ __global__ __launch_bounds__(256, BIOEM_FAST_WAVES_PER_SIMD) void k_compare_fast
   const int oc = oc_valid ? oc_raw : a.nOC - 1;
   const size_t M = (size_t) N * H;
   // buffer descriptors built from wave-uniform values only (blockIdx / readfirstlane'd wave id)
+  // timing-only ablation builds (never shipped): a zero-record descriptor drops the loads of one operand while
+  // the instruction stream and waits stay (cdna_hip_programming.md, profiling: pricing one buffer's traffic)
+#ifndef BIOEM_ABLATE_F
+#define BIOEM_ABLATE_F 0
+#endif
+#ifndef BIOEM_ABLATE_C
+#define BIOEM_ABLATE_C 0
+#endif
   const auto rsrcF = __builtin_amdgcn_make_buffer_rsrc(const_cast<float2 *>(a.ref + (size_t) p * M), 0,
-                                                       (int) (M * sizeof(float2)), 0x00020000);
+                                                       BIOEM_ABLATE_F ? 0 : (int) (M * sizeof(float2)), 0x00020000);
   const auto rsrcC = __builtin_amdgcn_make_buffer_rsrc(const_cast<float2 *>(a.conv + (size_t) oc * M), 0,
-                                                       (int) (M * sizeof(float2)), 0x00020000);
+                                                       BIOEM_ABLATE_C ? 0 : (int) (M * sizeof(float2)), 0x00020000);
 
   // window lanes
   const int nd = a.nd;
@@ -898,31 +981,37 @@ __global__ __launch_bounds__(256, BIOEM_FAST_WAVES_PER_SIMD) void k_compare_fast
   }
 
   const int nblk = (H + 63) / 64;
+  // Operand stream (software pipelined across k1 iterations AND column blocks): the (k1, k2-pair) loads of a
+  // lane walk t = k1*16 + k2p with a constant stride of H float4; a 4-deep ring of (F, C) pairs keeps 8 dwordx4
+  // loads (8 KiB per wave) in flight, re-issued as soon as a slot is consumed.  The ring runs on into the first
+  // rows of the NEXT column block, so those loads fly during the T exchange / window phase of this block.
+  // Addressing: buffer loads -- 128-bit descriptor (SGPRs), one 32-bit lane offset (VGPR), row offset in an SGPR.
+  const int ttotal = 16 * N1;
+  const unsigned rowbytes = (unsigned) H * 16u;
+  u32x4 rf[4], rc[4];
+  {
+    const unsigned lo0 = (unsigned) (lane < H ? lane : H - 1) * 16u;
+#pragma unroll
+    for (int t = 0; t < 4; t++)
+    {
+      rf[t] = __builtin_amdgcn_raw_buffer_load_b128(rsrcF, lo0, (unsigned) t * rowbytes, 0);
+      rc[t] = __builtin_amdgcn_raw_buffer_load_b128(rsrcC, lo0, (unsigned) t * rowbytes, 0);
+    }
+  }
   for (int blk = 0; blk < nblk; blk++)
   {
     const int ky = blk * 64 + lane;
     const int kyc = ky < H ? ky : H - 1;
+    const unsigned laneoff = (unsigned) kyc * 16u;
+    const int kyn = ky + 64 < H ? ky + 64 : H - 1;
+    const unsigned laneoff_next = (unsigned) kyn * 16u;
+    const bool has_next = blk + 1 < nblk;
     float Tr[NW], Ti[NW];
 #pragma unroll
     for (int d = 0; d < NW; d++)
     {
       Tr[d] = 0.f;
       Ti[d] = 0.f;
-    }
-    // Software-pipelined operand stream: the (k1, k2-pair) loads of this lane walk t = k1*16 + k2p with a
-    // constant stride of H float4; a 4-deep ring of (F, C) pairs keeps 8 dwordx4 loads (8 KiB per wave) in
-    // flight, re-issued as soon as a slot is consumed -- also across the FFT of the previous k1.
-    // addressing: buffer loads -- 128-bit descriptor (SGPRs) of this particle / conv spectrum, one constant
-    // 32-bit lane offset (VGPR) and the row offset t*H*16 in an SGPR: no vector address arithmetic at all.
-    const int ttotal = 16 * N1;
-    const unsigned laneoff = (unsigned) kyc * 16u;
-    const unsigned rowbytes = (unsigned) H * 16u;
-    u32x4 rf[4], rc[4];
-#pragma unroll
-    for (int t = 0; t < 4; t++)
-    {
-      rf[t] = __builtin_amdgcn_raw_buffer_load_b128(rsrcF, laneoff, (unsigned) t * rowbytes, 0);
-      rc[t] = __builtin_amdgcn_raw_buffer_load_b128(rsrcC, laneoff, (unsigned) t * rowbytes, 0);
     }
     for (int k1 = 0; k1 < N1; k1++)
     {
@@ -939,23 +1028,28 @@ __global__ __launch_bounds__(256, BIOEM_FAST_WAVES_PER_SIMD) void k_compare_fast
         const float4 f = as_float4(rf[k2p & 3]);
         const float4 c = as_float4(rc[k2p & 3]);
         // X = conv * conj(ref)   (bioem.cpp:1452-1455)
-        xr[2 * k2p] = fmaf(c.x, f.x, c.y * f.y);
-        xi[2 * k2p] = fmaf(c.y, f.x, -(c.x * f.y));
-        xr[2 * k2p + 1] = fmaf(c.z, f.z, c.w * f.w);
-        xi[2 * k2p + 1] = fmaf(c.w, f.z, -(c.z * f.w));
+        xr[FFT_IN(2 * k2p)] = fmaf(c.x, f.x, c.y * f.y);
+        xi[FFT_IN(2 * k2p)] = fmaf(c.y, f.x, -(c.x * f.y));
+        xr[FFT_IN(2 * k2p + 1)] = fmaf(c.z, f.z, c.w * f.w);
+        xi[FFT_IN(2 * k2p + 1)] = fmaf(c.w, f.z, -(c.z * f.w));
         int tn = k1 * 16 + k2p + 4;
-        tn = tn < ttotal ? tn : ttotal - 1;
-        rf[k2p & 3] = __builtin_amdgcn_raw_buffer_load_b128(rsrcF, laneoff, (unsigned) tn * rowbytes, 0);
-        rc[k2p & 3] = __builtin_amdgcn_raw_buffer_load_b128(rsrcC, laneoff, (unsigned) tn * rowbytes, 0);
+        unsigned vo = laneoff;
+        if (tn >= ttotal)
+        { // last steps of this block: run on into the next block (or re-read the last row at the very end)
+          tn = has_next ? tn - ttotal : ttotal - 1;
+          vo = has_next ? laneoff_next : laneoff;
+        }
+        rf[k2p & 3] = __builtin_amdgcn_raw_buffer_load_b128(rsrcF, vo, (unsigned) tn * rowbytes, 0);
+        rc[k2p & 3] = __builtin_amdgcn_raw_buffer_load_b128(rsrcC, vo, (unsigned) tn * rowbytes, 0);
         __builtin_amdgcn_sched_barrier(0);
       }
-      fft32_inverse(xr, xi);
+      FFT_RUN(xr, xi);
       // recombination of the N1 sub-transforms for the displacement window only:
       //   T[dx] += w_N^(dx*k1) * y_k1[dx mod 32]
 #pragma unroll
       for (int d = -WD; d <= WD; d++)
       {
-        const int pos = bitrev5(d & 31);
+        const int pos = FFT_OUT(d & 31);
         const float2 w = wk[d + WD];
         float tr = Tr[d + WD], ti = Ti[d + WD];
         tr = fmaf(xr[pos], w.x, tr);
@@ -972,11 +1066,13 @@ __global__ __launch_bounds__(256, BIOEM_FAST_WAVES_PER_SIMD) void k_compare_fast
       wgt = 1.f;
     if (ky >= H)
       wgt = 0.f;
-    __syncthreads(); // previous block's window reads are done
+    // T block of THIS wave only: LDS operations of one wave execute in order, so a wave-level fence (no
+    // s_barrier) is enough; BIOEM_BLOCK_BARRIER=1 restores block barriers (keeps the 4 waves in lock-step)
+    WAVE_OR_BLOCK_SYNC(); // previous block's window reads are done
 #pragma unroll
     for (int d = 0; d < NW; d++)
       Tl[d * TS + lane] = make_float2(Tr[d] * wgt, Ti[d] * wgt);
-    __syncthreads();
+    WAVE_OR_BLOCK_SYNC();
     const int idx0 = (int) (((long long) blk * 64 * step) % N);
     if (is_static)
       window_accumulate<NR, true>(Tl, twl, N, step, idx0, rowoff, nr, acc);
