@@ -1631,6 +1631,8 @@ int bioem_hip_create(bioem_hip_handle *out, int device, const bioem_hip_param_de
     OB = 1;
   if (OB > 64)
     OB = 64;
+  if (getenv("BIOEM_BATCH_ORIENTATIONS")) // tuning knob: orientations per batch (conv buffer = OB*nCTF spectra)
+    OB = std::max(1, std::min(OB, atoi(getenv("BIOEM_BATCH_ORIENTATIONS"))));
   if (OB > nAngles)
     OB = nAngles;
   h->OB = OB;
