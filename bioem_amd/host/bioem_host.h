@@ -67,6 +67,15 @@ int ctf_kernels(int N, float pixelSize, bool usepsf, float startAmp, float endAm
 float volume_element(float voluang, int gridSpaceCenter, int maxDisplaceCenter, float pixelSize, int nAmp,
                      float gridEnvelop, float gridPhase, float sigB, float sigDef, float sigAmp);
 
+// MRC header fields used by the readers (include/mrc.h of the reference): endianness guessed from header range
+// violations, data start at 1024 + nsymbt bytes
+struct MrcHeader
+{
+  int nc, nr, ns, mode, nsymbt, swap;
+};
+MrcHeader mrc_read_header(const char *file);
+unsigned int mrc_bswap32(unsigned int v);
+
 struct Model
 {
   std::vector<bioem_hip_model_point> points;
@@ -75,6 +84,7 @@ struct Model
   void readModel(const InputParams &p, const char *file); // model.cpp:674-710
   void readTextFile(const InputParams &p, const char *file);
   void readPDBFile(const char *file);
+  void readMRCFile(const InputParams &p, const char *file); // model.cpp:332-416
   void centerDensityMass();
 };
 

@@ -82,14 +82,17 @@ int bioem_host_setup_from_files(const char *paramfile, const char *anglefile, bi
 }
 
 // model readers: returns the number of points (fills up to cap), NormDen through *normden
-int bioem_host_read_model(const char *file, int isPDB, int nocentermass, bioem_hip_model_point *pts, int cap,
-                          float *normden)
+// isPDB: 0 text, 1 PDB, 2 MRC density map (pixelSize needed for the voxel positions)
+int bioem_host_read_model(const char *file, int isPDB, int nocentermass, float pixelSize, bioem_hip_model_point *pts,
+                          int cap, float *normden)
 {
   bioem_host::InputParams P;
   P.nocentermass = nocentermass;
   P.ignorePDB = true;
+  P.pixelSize = pixelSize;
   bioem_host::Model m;
-  m.readPDB = isPDB;
+  m.readPDB = (isPDB == 1);
+  m.readModelMRC = (isPDB == 2);
   m.readModel(P, file);
   for (int i = 0; i < (int) m.points.size() && i < cap; i++)
     pts[i] = m.points[i];

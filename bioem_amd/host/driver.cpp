@@ -73,6 +73,7 @@ int Driver::readOptions(int ac, char **av)
     printf("  --Inputfile arg        (Mandatory) Name of input parameter file\n");
     printf("  --ReadOrientation arg  (Optional) Read file name containing orientations\n");
     printf("  --ReadPDB              (Optional) If reading model file in PDB format\n");
+    printf("  --ReadModelMRC         (Optional) If reading model file in MRC format\n");
     printf("  --ReadMRC              (Optional) If reading particle file in MRC format\n");
     printf("  --ReadMultipleMRC      (Optional) If reading multiple MRCs\n");
     printf("  --OutputFile arg       (Optional) For changing the outputfile name\n");
@@ -124,7 +125,10 @@ int Driver::readOptions(int ac, char **av)
       model.readPDB = true;
     }
     else if (name == "ReadModelMRC")
+    {
+      std::cout << "Reading model file in MRC format.\n";
       model.readModelMRC = true;
+    }
     else if (name == "ReadOrientation")
     {
       std::cout << "Reading Orientation from file: " << optarg << "\n";

@@ -140,6 +140,53 @@ void Model::readPDBFile(const char *file)
   std::cout << "Protein structure read from PDB\n";
 }
 
+// density map as a model (model.cpp:332-416): every voxel becomes a point of radius 2*pixelSize whose
+// "density" is the voxel value; voxel (i,j,k), counted from 1 in file order i slowest, sits at
+// ((i - nx/2)*px, (j - ny/2)*px, (k - nz/2)*px).
+void Model::readMRCFile(const InputParams &p, const char *file)
+{
+  const std::string name(file);
+  if (name.find(".mrc") > name.find_last_not_of(" \t"))
+    warn("MRC extension NOT detected in file name: %s. Are you sure you want to read an MRC?", file);
+  const MrcHeader h = mrc_read_header(file);
+  if (h.mode != 2)
+    fatal("MRC mode: %d. Currently mode 2 is the only one allowed", h.mode);
+  const int nx = h.nc, ny = h.nr, nz = h.ns;
+  const size_t total = (size_t) nx * ny * nz;
+  FILE *f = fopen(file, "rb");
+  if (!f)
+    fatal("Opening MRC: %s", file);
+  if (fseek(f, 1024 + (long) h.nsymbt, SEEK_SET) != 0)
+    fatal("Converting Data: %s", file);
+  std::vector<unsigned int> raw(total);
+  if (fread(raw.data(), 4, total, f) != total)
+    fatal("Converting Data: %s", file);
+  fclose(f);
+  points.clear();
+  points.reserve(total);
+  NormDen = 0.f;
+  size_t e = 0;
+  for (int i = 1; i <= nx; i++)
+    for (int j = 1; j <= ny; j++)
+      for (int k = 1; k <= nz; k++, e++)
+      {
+        unsigned int v = raw[e];
+        if (h.swap)
+          v = mrc_bswap32(v);
+        float c;
+        memcpy(&c, &v, 4);
+        bioem_hip_model_point q{};
+        q.pos[0] = (float) ((i - nx / 2.0) * p.pixelSize);
+        q.pos[1] = (float) ((j - ny / 2.0) * p.pixelSize);
+        q.pos[2] = (float) ((k - nz / 2.0) * p.pixelSize);
+        q.radius = (float) (2.0 * p.pixelSize);
+        q.density = c;
+        NormDen += q.density;
+        points.push_back(q);
+      }
+  std::cout << "Protein structure read from MRC\n";
+}
+
 void Model::centerDensityMass()
 {
   float r[3] = {0.f, 0.f, 0.f};
@@ -158,7 +205,7 @@ void Model::readModel(const InputParams &p, const char *file)
   if (readPDB)
     readPDBFile(file);
   else if (readModelMRC)
-    fatal("--ReadModelMRC is not supported by this build (text and PDB models only)");
+    readMRCFile(p, file);
   else
     readTextFile(p, file);
   std::cout << "Total Number of Voxels " << points.size();

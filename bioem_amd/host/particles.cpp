@@ -72,11 +72,6 @@ void ParticleStack::readTextMaps(const char *file)
 
 namespace
 {
-struct MrcHeader
-{
-  int nc, nr, ns, mode, nsymbt, swap;
-};
-
 unsigned int bswap32(unsigned int v) { return (v >> 24) | ((v >> 8) & 0xff00u) | ((v << 8) & 0xff0000u) | (v << 24); }
 
 int range_violations(const unsigned int *w, int swap)
@@ -105,7 +100,9 @@ int range_violations(const unsigned int *w, int swap)
   return n;
 }
 
-MrcHeader read_header(const char *file)
+} // namespace
+
+MrcHeader mrc_read_header(const char *file)
 {
   FILE *f = fopen(file, "rb");
   if (!f)
@@ -141,11 +138,12 @@ MrcHeader read_header(const char *file)
   h.nsymbt = I(23);
   return h;
 }
-} // namespace
+
+unsigned int mrc_bswap32(unsigned int v) { return bswap32(v); }
 
 static void read_one_mrc(ParticleStack &S, const InputParams &p, const char *file)
 {
-  const MrcHeader h = read_header(file);
+  const MrcHeader h = mrc_read_header(file);
   printf("\n+++++++++++++++++++++++++++++++++++++++++++\n");
   printf("Reading Information from MRC: %s \n", file);
   printf("Number Columns  = %8d \n", h.nc);

@@ -80,13 +80,16 @@ def setup_from_files(paramfile, anglefile=None):
     return S, angles, ref, par
 
 
-def read_model(path, isPDB=False, nocentermass=False, cap=1 << 20):
+def read_model(path, isPDB=False, nocentermass=False, cap=1 << 20, isMRC=False, pixelSize=1.0):
     L = load_host_library()
-    L.bioem_host_read_model.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_float)]
+    L.bioem_host_read_model.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_int,
+                                        C.POINTER(C.c_float)]
     L.bioem_host_read_model.restype = C.c_int
     pts = np.zeros(cap, dtype=POINT_DTYPE)
     nd = C.c_float()
-    n = L.bioem_host_read_model(path.encode(), int(isPDB), int(nocentermass), pts.ctypes.data, cap, C.byref(nd))
+    kind = 2 if isMRC else int(bool(isPDB))
+    n = L.bioem_host_read_model(path.encode(), kind, int(nocentermass), float(pixelSize), pts.ctypes.data, cap,
+                                C.byref(nd))
     return pts[:n].copy(), np.float32(nd.value)
 
 

@@ -105,6 +105,46 @@ def test_model_reader_text_and_pdb(tmp_path):
     assert np.allclose(pts["pos"][1], [-1.5, 2.25, 3.125])
 
 
+def _write_mrc_volume(path, vol, big_endian=False, nsymbt=0):
+    e = ">" if big_endian else "<"
+    ns, nr, nc = vol.shape
+    hdr = np.zeros(256, dtype=e + "i4")
+    hdr[0:4] = [nc, nr, ns, 2]
+    hdr[7:10] = [nc, nr, ns]
+    hdr[23] = nsymbt
+    raw = hdr.tobytes()
+    raw = raw[:40] + struct.pack(e + "6f", 10., 10., 10., 90., 90., 90.) + raw[64:]
+    with open(path, "wb") as f:
+        f.write(raw + b"\0" * nsymbt + vol.astype(e + "f4").tobytes())
+
+
+@pytest.mark.parametrize("big_endian", [False, True])
+def test_model_reader_mrc_density_map(tmp_path, big_endian):
+    """--ReadModelMRC (reference model.cpp:332-416): every voxel a point of radius 2*px at
+    ((i - nx/2) px, (j - ny/2) px, (k - nz/2) px), i,j,k from 1, file order with i slowest."""
+    from bioem_amd import hostlib
+    rng = np.random.default_rng(3)
+    nx, ny, nz = 4, 5, 6                       # header nc, nr, ns
+    vals = rng.uniform(0.0, 2.0, size=nx * ny * nz).astype(np.float32)
+    path = str(tmp_path / "vol.mrc")
+    _write_mrc_volume(path, vals.reshape(nz, ny, nx), big_endian, nsymbt=16)   # raw order == file order
+    px = np.float32(1.5)
+    pts, nd = hostlib.read_model(path, isMRC=True, nocentermass=True, pixelSize=px)
+    assert len(pts) == nx * ny * nz
+    e = 0
+    acc = np.float32(0)
+    for i in range(1, nx + 1):
+        for j in range(1, ny + 1):
+            for k in range(1, nz + 1):
+                exp = np.array([(i - nx / 2.0) * float(px), (j - ny / 2.0) * float(px), (k - nz / 2.0) * float(px)],
+                               dtype=np.float32)
+                assert np.array_equal(pts["pos"][e], exp)
+                assert pts["density"][e] == vals[e] and pts["radius"][e] == np.float32(2.0 * float(px))
+                acc = np.float32(acc + vals[e])
+                e += 1
+    assert nd == acc
+
+
 def test_particle_reader_text(tmp_path):
     from bioem_amd import hostlib
     case = load_case("g3_n32_trace")

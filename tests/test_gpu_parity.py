@@ -434,3 +434,45 @@ def test_config3_shape_ten_ctfs_two_shards():
     want, _ = S.run(1)
     assert_same_posterior(S, merged, want)
     E.close()
+
+
+def test_cli_model_formats_pdb_and_mrc(tmp_path):
+    """--ReadPDB and --ReadModelMRC through the CLI against the oracle fed with the same points."""
+    from bioem_amd import hostlib
+    case, _ = setup_for("g3_n32_trace")
+    d = tmp_path
+    iof.write_text_particles(str(d / "particles.txt"), case["maps"])
+    with open(d / "orient.txt", "w") as f:
+        f.write("%d\n" % len(case["orient_lines"]) + "\n".join(case["orient_lines"]) + "\n")
+    exe = os.path.join(ROOT, "bioem_amd", "bin", "bioEM")
+    # PDB: C-alpha trace built from the golden model coordinates with cycling residue names
+    names = ["GLY", "ALA", "TRP", "LYS", "GLU", "PHE"]
+    with open(d / "m.pdb", "w") as f:
+        for i, p in enumerate(case["model"]):
+            f.write("ATOM  %5d  CA  %s A%4d    %8.3f%8.3f%8.3f  1.00  0.00           C\n"
+                    % (i + 1, names[i % 6], i + 1, p[0], p[1], p[2]))
+        f.write("END\n")
+    # MRC density map: 6^3 voxels
+    rng = np.random.default_rng(8)
+    vol = rng.uniform(0.1, 1.0, size=(6, 6, 6)).astype(np.float32)
+    hdr = np.zeros(256, dtype="<i4")
+    hdr[0:4] = [6, 6, 6, 2]
+    hdr[7:10] = [6, 6, 6]
+    with open(d / "v.mrc", "wb") as f:
+        f.write(hdr.tobytes() + vol.tobytes())
+    for flag, mfile, kind in (("--ReadPDB", "m.pdb", dict(isPDB=True)), ("--ReadModelMRC", "v.mrc", dict(isMRC=True))):
+        r = subprocess.run([exe, "--Modelfile", mfile, "--Particlesfile", "particles.txt", "--Inputfile",
+                            os.path.join(case["dir"], "param.txt"), "--ReadOrientation", "orient.txt", flag,
+                            "--OutputFile", "out_" + mfile], cwd=str(d), env=dict(os.environ, BIOEM_GPUS="1"),
+                           stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
+        assert r.returncode == 0, r.stdout[-2000:]
+        pts, nd = hostlib.read_model(str(d / mfile), nocentermass=True, pixelSize=case["P"]["pixelSize"], **kind)
+        arr = np.concatenate([pts["pos"].astype(np.float64), pts["radius"][:, None].astype(np.float64),
+                              pts["density"][:, None].astype(np.float64)], axis=1)
+        S = orc.Setup(case["P"], arr, case["maps"], case["orient_lines"])
+        want, _ = S.run(1)
+        ref = iof.parse_output_probabilities(orc.format_output_probabilities(S, want))
+        mine = iof.parse_output_probabilities(open(d / ("out_" + mfile)).read())
+        for g, m in zip(ref, mine):
+            assert abs(g["logp"] - m["logp"]) <= max(ABS_TOL, REL_TOL * abs(g["logp"]))
+            assert (g["angles"], g["ctf"], g["cx"], g["cy"]) == (m["angles"], m["ctf"], m["cx"], m["cy"])
