@@ -15,6 +15,22 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run by the driver on the GPU box)")
 
 
+def _ensure_built():
+    """Build the in-tree native pieces when a fresh checkout has none of them yet (hipcc cross-compiles gfx950
+    without a GPU).  The .so files are git-ignored; on the GPU box they arrive prebuilt with the snapshot."""
+    import subprocess
+    need_engine = not all(os.path.exists(os.path.join(ROOT, "bioem_amd", p)) for p in
+                          ("lib/libbioem_hip.so", "lib/libbioem_host.so", "bin/bioEM"))
+    if need_engine:
+        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "bioem_amd", "csrc"), "all"])
+    if not os.path.exists(os.path.join(ROOT, "oracle", "liboracle.so")):
+        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "oracle"])
+
+
+def pytest_sessionstart(session):
+    _ensure_built()
+
+
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
