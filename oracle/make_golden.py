@@ -163,13 +163,60 @@ def case_table():
                         kw=[("CTF_B_ENV", [20.0, 200.0, 3]), ("CTF_DEFOCUS", [1.0, 3.0, 2]),
                             ("CTF_AMPLITUDE", [0.1, 0.1, 1]), ("DISPLACE_CENTER", [6, 1])],
                         algos=[1, 2], snr=0.1, maxshift=4, seed=110)
+    # G11: Euler-angle LIST with per-orientation priors (PRIOR_ANGLES) and WRITE_PROB_ANGLES
+    C["g11_n32_eulerlist"] = dict(N=32, px=3.0, nP=2, npts=25, extent=25.0, rad=(3.2, 3.4), orient=("eulerlist", 14),
+                                  kw=[("PRIOR_ANGLES", []), ("CTF_B_ENV", [50.0, 150.0, 2]),
+                                      ("CTF_DEFOCUS", [1.0, 2.0, 2]), ("CTF_AMPLITUDE", [0.1, 0.1, 1]),
+                                      ("DISPLACE_CENTER", [3, 1]), ("WRITE_PROB_ANGLES", [4])],
+                                  algos=[1], snr=0.3, maxshift=2, seed=111)
+    # G12: NO_CENTEROFMASS, ELECTRON_WAVELENGTH, 3-point amplitude grid, BIOEM_DEBUG_BREAK truncation
+    C["g12_n32_misc"] = dict(N=32, px=3.0, nP=3, npts=25, extent=20.0, rad=(3.2, 3.4), orient=("list", 16),
+                             kw=[("NO_CENTEROFMASS", []), ("ELECTRON_WAVELENGTH", [0.0251]),
+                                 ("CTF_B_ENV", [50.0, 150.0, 2]), ("CTF_DEFOCUS", [1.0, 2.0, 2]),
+                                 ("CTF_AMPLITUDE", [0.1, 0.4, 3]), ("DISPLACE_CENTER", [4, 2])],
+                             algos=[1, 2], snr=0.3, maxshift=2, seed=112, env={"BIOEM_DEBUG_BREAK": "9"})
+    # G13: PSF mode with WRITE_CTF_PARAM
+    C["g13_n32_psf_writectf"] = dict(N=32, px=3.0, nP=2, npts=25, extent=25.0, rad=(3.2, 3.4), orient=("list", 8),
+                                     kw=[("USE_PSF", []), ("WRITE_CTF_PARAM", []), ("PSF_AMPLITUDE", [0.1, 0.3, 2]),
+                                         ("PSF_ENVELOPE", [0.02, 0.08, 2]), ("PSF_PHASE", [0.01, 0.05, 2]),
+                                         ("DISPLACE_CENTER", [3, 1])],
+                                     algos=[1], snr=0.3, maxshift=2, seed=113)
+    # G14: particles from an MRC stack (--ReadMRC): transposed store + float z-score of the reference reader
+    C["g14_n32_mrc"] = dict(N=32, px=3.0, nP=3, npts=25, extent=25.0, rad=(3.2, 3.4), orient=("list", 10),
+                            kw=[("CTF_B_ENV", [50.0, 150.0, 2]), ("CTF_DEFOCUS", [1.0, 2.0, 2]),
+                                ("CTF_AMPLITUDE", [0.1, 0.1, 1]), ("DISPLACE_CENTER", [3, 1])],
+                            algos=[1], snr=0.3, maxshift=2, seed=114, particles="mrc")
+    # G15: MRC stack with NO_MAP_NORM
+    C["g15_n32_mrc_nonorm"] = dict(N=32, px=3.0, nP=2, npts=25, extent=25.0, rad=(3.2, 3.4), orient=("list", 6),
+                                   kw=[("NO_MAP_NORM", []), ("CTF_B_ENV", [50.0, 150.0, 2]),
+                                       ("CTF_DEFOCUS", [1.5, 1.5, 1]), ("CTF_AMPLITUDE", [0.1, 0.1, 1]),
+                                       ("DISPLACE_CENTER", [3, 1])],
+                                   algos=[1], snr=0.3, maxshift=2, seed=115, particles="mrc")
     return C
+
+
+def write_mrc_stack(path, data):
+    """mode-2 little-endian MRC stack: 1024-byte header (nc, nr, ns, mode, ...), no symmetry bytes."""
+    import struct
+    ns, nr, nc = data.shape
+    hdr = np.zeros(256, dtype="<i4")
+    hdr[0:4] = [nc, nr, ns, 2]
+    hdr[7:10] = [nc, nr, ns]
+    raw = hdr.tobytes()
+    raw = raw[:40] + struct.pack("<6f", 100., 100., 100., 90., 90., 90.) + raw[64:]
+    with open(path, "wb") as f:
+        f.write(raw + data.astype("<f4").tobytes())
 
 
 def orientation_rots(spec, qlines):
     if spec[0] == "list":
         qs = np.array([[float(ln[c:c + 12]) for c in range(0, 48, 12)] for ln in qlines[:spec[1]]])
         return [quat_rotmat(q) for q in qs]
+    if spec[0] == "eulerlist":
+        rng = np.random.default_rng(4242)
+        ang = np.stack([rng.uniform(-np.pi, np.pi, spec[1]), np.arccos(rng.uniform(-1, 1, spec[1])),
+                        rng.uniform(-np.pi, np.pi, spec[1])], axis=1)
+        return [euler_rotmat(*a) for a in np.round(ang, 8)]
     if spec[0] == "eulergrid":
         na, nb = spec[1], spec[2]
         rots = []
@@ -213,16 +260,36 @@ def prepare():
         kw += c["kw"]
         iof.write_param_file(os.path.join(d, "param.txt"), kw)
         iof.write_text_model(os.path.join(d, "model.txt"), model)
-        iof.write_text_particles(os.path.join(d, "particles.txt"), maps)
+        pformat = c.get("particles", "text")
+        if pformat == "mrc":
+            # raw un-normalised counts in FILE order (section, row, column); the reader transposes and z-scores
+            raw = (2.5 * maps + 6.0).astype(np.float32)
+            write_mrc_stack(os.path.join(d, "particles.mrc"), raw)
+            maps = raw
+        else:
+            iof.write_text_particles(os.path.join(d, "particles.txt"), maps)
         orient_lines = []
         if c["orient"][0] == "list":
             orient_lines = qlines[:c["orient"][1]]
             with open(os.path.join(d, "orient.txt"), "w") as f:
                 f.write("%d\n" % len(orient_lines))
                 f.write("\n".join(orient_lines) + "\n")
+        if c["orient"][0] == "eulerlist":
+            rng2 = np.random.default_rng(4242)
+            n = c["orient"][1]
+            ang = np.stack([rng2.uniform(-np.pi, np.pi, n), np.arccos(rng2.uniform(-1, 1, n)),
+                            rng2.uniform(-np.pi, np.pi, n)], axis=1)
+            ang = np.round(ang, 8)
+            pri = np.round(np.random.default_rng(77).uniform(0.2, 1.0, n), 8)
+            orient_lines = ["".join("%12.8f" % v for v in a) + "%12.8f" % pr for a, pr in zip(ang, pri)]
+            with open(os.path.join(d, "orient.txt"), "w") as f:
+                f.write("%d\n" % n)
+                f.write("\n".join(orient_lines) + "\n")
         np.savez_compressed(os.path.join(d, "inputs.npz"), model=model, maps=maps,
                             orient_lines=np.array(orient_lines), N=c["N"], px=c["px"],
-                            algos=np.array(c["algos"]), trace=bool(c.get("trace", False)))
+                            algos=np.array(c["algos"]), trace=bool(c.get("trace", False)),
+                            particles=pformat, env_keys=np.array(list(c.get("env", {}).keys())),
+                            env_vals=np.array(list(c.get("env", {}).values())))
         print("prepared", name, maps.shape)
 
 
@@ -239,9 +306,16 @@ def run():
             for exe, tag in ([(binary, "")] + ([(binary_trace, "_trace")] if bool(inp["trace"]) else [])):
                 env = dict(os.environ, OMP_NUM_THREADS="1", BIOEM_ALGO=str(algo), BIOEM_DEBUG_OUTPUT="0")
                 env.pop("GPU", None)
+                if "env_keys" in inp.files:
+                    for k_, v_ in zip(inp["env_keys"], inp["env_vals"]):
+                        env[str(k_)] = str(v_)
+                pformat = str(inp["particles"]) if "particles" in inp.files else "text"
+                pfile = "particles.mrc" if pformat == "mrc" else "particles.txt"
                 cmd = [exe, "--Modelfile", os.path.join(d, "model.txt"), "--Particlesfile",
-                       os.path.join(d, "particles.txt"), "--Inputfile", os.path.join(d, "param.txt"),
+                       os.path.join(d, pfile), "--Inputfile", os.path.join(d, "param.txt"),
                        "--OutputFile", "Output_Probabilities_algo%d%s" % (algo, tag)]
+                if pformat == "mrc":
+                    cmd.append("--ReadMRC")
                 if os.path.exists(os.path.join(d, "orient.txt")):
                     cmd += ["--ReadOrientation", os.path.join(d, "orient.txt")]
                 r = subprocess.run(cmd, cwd=out, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)

@@ -265,14 +265,20 @@ def _libm_acosf(x):
 def orientations(P, orient_lines=None):
     """param.cpp:988-1334.  Returns (angles[n,4] f32, isQuat, voluang f32)."""
     priorMod = P["priorMod"]
+    P["angprior"] = None
     if orient_lines is not None and len(orient_lines):
         n = len(orient_lines)
         ang = np.zeros((n, 4), dtype=f32)
         ncol = 4 if P["doquater"] else 3
+        pri = np.zeros(n, dtype=f32)
         for i, ln in enumerate(orient_lines):
             ln = str(ln)
             for c in range(ncol):
                 ang[i, c] = f32(float(ln[12 * c:12 * c + 12]))
+            if P["yespriorAngles"]:   # param.cpp:1098-1106 / 1296-1304: one more 12-char column
+                pri[i] = f32(float(ln[12 * ncol:12 * ncol + 12]))
+        if P["yespriorAngles"]:
+            P["angprior"] = pri
         voluang = f32((1. / float(f32(n))) * float(priorMod))  # :1131,1324 (double expr -> float)
         return ang, P["doquater"], voluang
     if not P["doquater"]:
@@ -330,7 +336,7 @@ def model_from_array(arr, nocentermass=False):
 class Setup:
     """Everything configure()/precalculate() prepares (bioem.cpp:438-622) for a given input set."""
 
-    def __init__(self, P, model_arr, maps, orient_lines=None):
+    def __init__(self, P, model_arr, maps, orient_lines=None, debug_break=None):
         L = lib()
         self.P = P
         N = P["N"]
@@ -368,6 +374,15 @@ class Setup:
         pd.volu = L.orc_volu(self.voluang, P["gridSpace"], P["maxD"], self.px, P["nAmp"], steps[2], steps[1],
                              pd.sigmaPriorbctf, pd.sigmaPriordefo, pd.sigmaPrioramp)
         self.pd = pd
+        if debug_break is not None:
+            # BIOEM_DEBUG_BREAK (bioem.cpp:518-525): counts truncated AFTER volu was computed with the full ones
+            if self.nAngles > debug_break:
+                self.nAngles = debug_break
+                self.angles = np.ascontiguousarray(self.angles[:debug_break])
+            if self.nCTF > debug_break:
+                self.nCTF = debug_break
+                self.refCTF = np.ascontiguousarray(self.refCTF[:debug_break])
+                self.ctfParam = np.ascontiguousarray(self.ctfParam[:debug_break])
         maps = np.ascontiguousarray(maps, dtype=f32)
         self.nMaps = len(maps)
         self.maps = maps
@@ -414,6 +429,27 @@ class Setup:
 
     def final_logp(self, pm):
         return lib().orc_final_logp(C.byref(self.pd), float(pm["Total"]), float(pm["Constoadd"]))
+
+
+def mrc_reader_maps(stack, notnormmap=False):
+    """What the reference's MRC particle reader delivers for a mode-2 stack given in FILE order
+    [section][row][column] (map.cpp:808-845): stored transposed, z-scored with float accumulators in file order."""
+    stack = np.asarray(stack, dtype=f32)
+    ns, nr, nc = stack.shape
+    out = np.zeros((ns, nc, nr), dtype=f32)
+    for s_ in range(ns):
+        st = f32(0)
+        st2 = f32(0)
+        for v in stack[s_].ravel():
+            st = f32(st + v)
+            st2 = f32(st2 + f32(v * v))
+        m = np.ascontiguousarray(stack[s_].T)
+        if not notnormmap:
+            st = f32(st / f32(nr * nc))
+            sd = f32(np.sqrt(f32(f32(st2 / f32(nr * nc)) - f32(st * st))))
+            m = (m / sd - f32(st / sd)).astype(f32)
+        out[s_] = m
+    return out
 
 
 def merge(shards):
@@ -476,6 +512,12 @@ def format_output_probabilities(S, pmap):
             s += "%s [1/A²] %s [1/A²] " % (f4(c[1]), f4(c[2]))
         s += "%d [pix] %d [pix] %s [] %s [] \n" % (pm["cent_x"], pm["cent_y"], f4(pm["norm"]), f4(pm["mu"]))
         o.append(s)
+        if P["writeCTF"] and P["usepsf"]:
+            # bioem.cpp:1225-1242
+            denomi = f32(f32(c[1] * c[1]) + f32(c[2] * c[2]))
+            v1 = 2 * math.pi * float(c[1]) / float(denomi) / float(P["elecwavel"]) * 0.0001
+            v2 = 4 * math.pi * math.pi * float(c[2]) / float(denomi)
+            o.append("RefMap: %d CTFMaxParam: %s [micro-m] %s [A²] \n" % (i, f4(v1), f4(v2)))
     return "".join(o)
 
 
@@ -494,6 +536,8 @@ def ang_prob_rows(S, pmap, pang):
             elif q[0][0] < logp:
                 heapq.heapreplace(q, (logp, io))
         rows = sorted(q, reverse=True)
-        out[m] = [dict(orient=io, logp=lp, logsum=math.log(pang[io, m]["forAngles"]),
-                       const=float(pang[io, m]["ConstAngle"]), numconst=const) for lp, io in rows]
+        pri = S.P.get("angprior")
+        out[m] = [dict(orient=io, logp=lp + (float(pri[io]) if pri is not None else 0.0),
+                       logsum=math.log(pang[io, m]["forAngles"]), const=float(pang[io, m]["ConstAngle"]),
+                       numconst=const, prior=(float(pri[io]) if pri is not None else None)) for lp, io in rows]
     return out

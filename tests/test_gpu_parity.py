@@ -233,45 +233,72 @@ def test_invalid_configuration_is_rejected():
     E.close()
 
 
-def test_cli_end_to_end_against_reference_outputs(tmp_path):
-    """The drop-in CLI (--Modelfile/--Particlesfile/--Inputfile[/--ReadOrientation]) on the golden inputs:
-    Output_Probabilities parsed and compared with the reference's own file."""
+def _write_mrc_stack(path, data):
+    import struct
+    ns, nr, nc = data.shape
+    hdr = np.zeros(256, dtype="<i4")
+    hdr[0:4] = [nc, nr, ns, 2]
+    hdr[7:10] = [nc, nr, ns]
+    raw = hdr.tobytes()
+    raw = raw[:40] + struct.pack("<6f", 100., 100., 100., 90., 90., 90.) + raw[64:]
+    with open(path, "wb") as f:
+        f.write(raw + data.astype("<f4").tobytes())
+
+
+CLI_CASES = ["g10_n64", "g9_n35_odd", "g4_n32_angles", "g5_n32_psf", "g11_n32_eulerlist", "g12_n32_misc",
+             "g13_n32_psf_writectf", "g14_n32_mrc", "g15_n32_mrc_nonorm"]
+
+
+@pytest.mark.parametrize("name", CLI_CASES)
+def test_cli_end_to_end_against_reference_outputs(name, tmp_path):
+    """The drop-in CLI (--Modelfile/--Particlesfile/--Inputfile[/--ReadOrientation][/--ReadMRC]) on the golden
+    inputs, with the same files, options and environment the reference was run with: Output_Probabilities /
+    ANG_PROB parsed and compared with the reference's own files; the header block must be byte-identical."""
     exe = os.path.join(ROOT, "bioem_amd", "bin", "bioEM")
     assert os.path.exists(exe), "CLI not built"
-    for name in ["g10_n64", "g9_n35_odd", "g4_n32_angles", "g5_n32_psf"]:
-        case, S = setup_for(name)
-        d = tmp_path / name
-        d.mkdir()
-        iof.write_text_model(str(d / "model.txt"), case["model"])
+    case, S = setup_for(name)
+    d = tmp_path
+    iof.write_text_model(str(d / "model.txt"), case["model"])
+    if case["particles"] == "mrc":
+        _write_mrc_stack(str(d / "particles.mrc"), case["raw_maps"])
+        pargs = ["--Particlesfile", "particles.mrc", "--ReadMRC"]
+    else:
         iof.write_text_particles(str(d / "particles.txt"), case["maps"])
-        cmd = [exe, "--Modelfile", "model.txt", "--Particlesfile", "particles.txt", "--Inputfile",
-               os.path.join(case["dir"], "param.txt"), "--OutputFile", "out.txt"]
-        if case["orient_lines"]:
-            with open(d / "orient.txt", "w") as f:
-                f.write("%d\n" % len(case["orient_lines"]) + "\n".join(case["orient_lines"]) + "\n")
-            cmd += ["--ReadOrientation", "orient.txt"]
-        for algo in case["algos"]:
-            env = dict(os.environ, BIOEM_ALGO=str(algo), BIOEM_GPUS="1")
-            r = subprocess.run(cmd, cwd=str(d), env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True,
-                               timeout=300)
-            assert r.returncode == 0, r.stdout[-2000:]
-            text = open(d / "out.txt").read()
-            gold_text = golden_output(case, algo)
-            # header block is byte-identical
-            assert text.split("\n\n")[0] == gold_text.split("\n\n")[0]
-            gold = iof.parse_output_probabilities(gold_text)
-            mine = iof.parse_output_probabilities(text)
-            assert len(gold) == len(mine)
-            for g, m in zip(gold, mine):
-                assert abs(g["logp"] - m["logp"]) <= max(ABS_TOL, REL_TOL * abs(g["logp"]))
-                assert (g["angles"], g["ctf"], g["cx"], g["cy"]) == (m["angles"], m["ctf"], m["cx"], m["cy"])
-                assert abs(g["norm"] - m["norm"]) <= 2e-4 and abs(g["mu"] - m["mu"]) <= 2e-4
-            if name == "g4_n32_angles":
-                ga = iof.parse_ang_prob(os.path.join(case["dir"], "ANG_PROB_algo%d" % algo))
-                ma = iof.parse_ang_prob(str(d / "ANG_PROB"))
-                for m_ in ga:
-                    for g, m in zip(ga[m_], ma[m_]):
-                        assert g["angles"] == m["angles"] and abs(g["logp"] - m["logp"]) <= 5e-3
+        pargs = ["--Particlesfile", "particles.txt"]
+    cmd = [exe, "--Modelfile", "model.txt", "--Inputfile", os.path.join(case["dir"], "param.txt"), "--OutputFile",
+           "out.txt"] + pargs
+    if case["orient_lines"]:
+        with open(d / "orient.txt", "w") as f:
+            f.write("%d\n" % len(case["orient_lines"]) + "\n".join(case["orient_lines"]) + "\n")
+        cmd += ["--ReadOrientation", "orient.txt"]
+    for algo in case["algos"]:
+        env = dict(os.environ, BIOEM_ALGO=str(algo), BIOEM_GPUS="1")
+        env.update(case["env"])
+        r = subprocess.run(cmd, cwd=str(d), env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True,
+                           timeout=300)
+        assert r.returncode == 0, r.stdout[-2000:]
+        text = open(d / "out.txt").read()
+        gold_text = golden_output(case, algo)
+        assert text.split("\n\n")[0] == gold_text.split("\n\n")[0]          # header block byte-identical
+        gold = iof.parse_output_probabilities(gold_text)
+        mine = iof.parse_output_probabilities(text)
+        assert len(gold) == len(mine)
+        for g, m in zip(gold, mine):
+            assert abs(g["logp"] - m["logp"]) <= max(ABS_TOL, REL_TOL * abs(g["logp"]))
+            assert (g["angles"], g["ctf"], g["cx"], g["cy"]) == (m["angles"], m["ctf"], m["cx"], m["cy"])
+            assert abs(g["norm"] - m["norm"]) <= 2e-4 and abs(g["mu"] - m["mu"]) <= 2e-4
+        gl = [ln for ln in gold_text.split("\n") if "CTFMaxParam" in ln]
+        ml = [ln for ln in text.split("\n") if "CTFMaxParam" in ln]
+        assert gl == ml                                                        # WRITE_CTF_PARAM lines
+        if S.pd.writeAngles:
+            ga = iof.parse_ang_prob(os.path.join(case["dir"], "ANG_PROB_algo%d" % algo))
+            ma = iof.parse_ang_prob(str(d / "ANG_PROB"))
+            assert sorted(ga) == sorted(ma)
+            for m_ in ga:
+                assert len(ga[m_]) == len(ma[m_])
+                for g, m in zip(ga[m_], ma[m_]):
+                    assert g["angles"] == m["angles"] and abs(g["logp"] - m["logp"]) <= 5e-3
+                    assert len(g["sep"]) == len(m["sep"])
 
 
 def test_cli_error_behaviour(tmp_path):

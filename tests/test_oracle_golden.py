@@ -67,8 +67,11 @@ def test_algo1_equals_algo2_when_grid_divides_maxd():
         assert (a["cent_x"], a["cent_y"], a["orient"], a["conv"]) == (b["cent_x"], b["cent_y"], b["orient"], b["conv"])
 
 
-def test_ang_prob_matches_reference():
-    case, S = setup_for("g4_n32_angles")
+@pytest.mark.parametrize("name", ["g4_n32_angles", "g11_n32_eulerlist"])
+def test_ang_prob_matches_reference(name):
+    """ANG_PROB: K best orientations per particle; with PRIOR_ANGLES the per-orientation prior is added to the
+    printed log P and appended as a column (bioem.cpp:1297-1311)."""
+    case, S = setup_for(name)
     for algo in case["algos"]:
         pmap, pang = S.run(algo)
         rows = orc.ang_prob_rows(S, pmap, pang)
@@ -78,11 +81,14 @@ def test_ang_prob_matches_reference():
             assert len(gold[m]) == len(rows[m]) == S.pd.writeAngles
             for g, r in zip(gold[m], rows[m]):
                 q = S.angles[r["orient"]]
-                assert g["angles"] == [float("%.4f" % v) for v in q]
+                nang = 4 if S.isQuat else 3
+                assert g["angles"] == [float("%.4f" % v) for v in q[:nang]]
                 assert abs(g["logp"] - r["logp"]) <= ABS_TOL
                 assert abs(g["sep"][0] - r["logsum"]) <= ABS_TOL
                 assert abs(g["sep"][1] - r["const"]) <= ABS_TOL
                 assert abs(g["sep"][2] - r["numconst"]) <= 1e-3
+                if r["prior"] is not None:
+                    assert abs(g["sep"][3] - r["prior"]) <= 1e-4
 
 
 def test_per_displacement_trace():
