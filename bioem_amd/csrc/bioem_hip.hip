@@ -148,9 +148,9 @@ namespace
 
 // ------------------------------------------------------------------------------------------------
 // layout of a half spectrum used by the comparison kernels
-//   fast   : kx = N1*k2 + k1  ->  float2 index ((k1*16 + (k2>>1))*H + ky)*2 + (k2&1)
-//            (lane = ky reads 16 B = two k2 of one k1 -> fully coalesced dwordx4, and the 32 inputs
-//             of one register FFT arrive as 16 such loads)
+//   fast   : N = N1*R (R = 32, 16 or 8), kx = N1*k2 + k1  ->  float2 index ((k1*R/2 + (k2>>1))*H + ky)*2 + (k2&1)
+//            (lane = ky reads 16 B = two k2 of one k1 -> fully coalesced dwordx4, and the R inputs
+//             of one register FFT arrive as R/2 such loads).  The `fast` argument carries R/2 (0 = generic).
 //   generic: reference layout kx*H + ky
 // ------------------------------------------------------------------------------------------------
 __host__ __device__ inline size_t layout_index(int fast, int N1, int H, int kx, int ky)
@@ -158,7 +158,7 @@ __host__ __device__ inline size_t layout_index(int fast, int N1, int H, int kx, 
   if (!fast)
     return (size_t) kx * H + ky;
   const int k1 = kx % N1, k2 = kx / N1;
-  return ((size_t) (k1 * 16 + (k2 >> 1)) * H + ky) * 2 + (k2 & 1);
+  return ((size_t) (k1 * fast + (k2 >> 1)) * H + ky) * 2 + (k2 & 1);
 }
 
 __global__ void k_reorder(const float2 *__restrict__ src, float2 *__restrict__ dst, int nImg, int N, int H, int fast,
@@ -699,18 +699,30 @@ __device__ __forceinline__ float4 as_float4(u32x4 v)
   return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
 }
 
-// 32-point inverse FFT, radix-2 decimation in time: input must be stored at the bit-reversed position
-// (element k2 at index bitrev5(k2)), output in natural order.  Twiddled butterflies use
+// R-point inverse FFT (R = 8, 16, 32), radix-2 decimation in time: input must be stored at the bit-reversed
+// position (element k2 at index bitrev<R>(k2)), output in natural order.  Twiddled butterflies use
 //   out0 = a + w*b  (4 FMAs),  out1 = 2a - out0  (2 FMAs)
 // i.e. 6 instead of 8 operations.
-__device__ __forceinline__ void fft32_inverse_dit(float (&xr)[32], float (&xi)[32])
+template <int R>
+__host__ __device__ constexpr int bitrevR(int n)
 {
+  int r = 0;
+  for (int b = 1, c = R >> 1; b < R; b <<= 1, c >>= 1)
+    if (n & b)
+      r |= c;
+  return r;
+}
+
+template <int R>
+__device__ __forceinline__ void fft_inverse_dit(float (&xr)[R], float (&xi)[R])
+{
+  constexpr int LOG2R = (R == 32) ? 5 : (R == 16) ? 4 : 3;
 #pragma unroll
-  for (int s = 0; s < 5; s++)
+  for (int s = 0; s < LOG2R; s++)
   {
     const int m = 1 << s;
 #pragma unroll
-    for (int b = 0; b < 32; b += 2 * m)
+    for (int b = 0; b < R; b += 2 * m)
     {
 #pragma unroll
       for (int j = 0; j < m; j++)
@@ -877,7 +889,7 @@ __device__ __forceinline__ void window_accumulate(const float2 *Tl, const float2
 }
 
 // ------------------------------------------------------------------------------------------------
-// fast comparison kernel: N = 32*N1, 2*maxD+1 <= 2*WD+1 <= 31.
+// fast comparison kernel: N = R*N1 with R = 32, 16 or 8 (the largest of those dividing N), 2*maxD+1 <= 2*WD+1 <= 31.
 // block = 4 waves = 4 consecutive (orientation*CTF) indices of ONE particle (the particle columns are then
 // served to waves 1..3 from L1); blockIdx.x = ocGroup * nMaps + particle, so concurrently resident blocks
 // share the same 4 conv spectra in L2.  Columns are processed in blocks of 64 (lane = column): register
@@ -885,6 +897,7 @@ __device__ __forceinline__ void window_accumulate(const float2 *Tl, const float2
 // (10.5 KiB for +-10 px => 3 blocks per CU, matching the VGPR-limited 3 waves per SIMD).
 // ------------------------------------------------------------------------------------------------
 // FFT flavour: decimation in time with 6-op butterflies (default) or the decimation-in-frequency original
+// (R = 32 only)
 #ifndef BIOEM_FFT_DIF
 #define BIOEM_FFT_DIF 0
 #endif
@@ -893,9 +906,9 @@ __device__ __forceinline__ void window_accumulate(const float2 *Tl, const float2
 #define FFT_OUT(n) bitrev5(n)
 #define FFT_RUN(xr, xi) fft32_inverse(xr, xi)
 #else
-#define FFT_IN(k) bitrev5(k)
+#define FFT_IN(k) bitrevR<R>(k)
 #define FFT_OUT(n) (n)
-#define FFT_RUN(xr, xi) fft32_inverse_dit(xr, xi)
+#define FFT_RUN(xr, xi) fft_inverse_dit<R>(xr, xi)
 #endif
 #ifndef BIOEM_BLOCK_BARRIER
 #define BIOEM_BLOCK_BARRIER 1
@@ -914,10 +927,11 @@ __device__ __forceinline__ void window_accumulate(const float2 *Tl, const float2
 #ifndef BIOEM_FAST_WAVES_PER_SIMD
 #define BIOEM_FAST_WAVES_PER_SIMD 3
 #endif
-template <int WD>
+template <int WD, int R>
 __global__ __launch_bounds__(256, (WD <= 10 ? BIOEM_FAST_WAVES_PER_SIMD : 2)) void k_compare_fast(const CompareArgs a)
 {
   constexpr int NW = 2 * WD + 1;
+  constexpr int R2 = R / 2; // rows (k2 pairs) per k1 step
   constexpr int NR = (WD <= 10) ? 7 : 16;
   constexpr int TS = 66; // T row stride in float2 (64 columns + 2 pad: row groups land on different banks)
   extern __shared__ __align__(16) unsigned char smem[];
@@ -986,7 +1000,7 @@ __global__ __launch_bounds__(256, (WD <= 10 ? BIOEM_FAST_WAVES_PER_SIMD : 2)) vo
   // loads (8 KiB per wave) in flight, re-issued as soon as a slot is consumed.  The ring runs on into the first
   // rows of the NEXT column block, so those loads fly during the T exchange / window phase of this block.
   // Addressing: buffer loads -- 128-bit descriptor (SGPRs), one 32-bit lane offset (VGPR), row offset in an SGPR.
-  const int ttotal = 16 * N1;
+  const int ttotal = R2 * N1;
   const unsigned rowbytes = (unsigned) H * 16u;
   u32x4 rf[4], rc[4];
   {
@@ -1015,7 +1029,7 @@ __global__ __launch_bounds__(256, (WD <= 10 ? BIOEM_FAST_WAVES_PER_SIMD : 2)) vo
     }
     for (int k1 = 0; k1 < N1; k1++)
     {
-      float xr[32], xi[32];
+      float xr[R], xi[R];
       // the 2*WD+1 recombination twiddles of this k1 are contiguous: a few wide scalar loads, issued early
       float2 wk[NW];
       const float2 *twk = a.twk + (size_t) k1 * NW;
@@ -1023,7 +1037,7 @@ __global__ __launch_bounds__(256, (WD <= 10 ? BIOEM_FAST_WAVES_PER_SIMD : 2)) vo
       for (int d = 0; d < NW; d++)
         wk[d] = twk[d];
 #pragma unroll
-      for (int k2p = 0; k2p < 16; k2p++)
+      for (int k2p = 0; k2p < R2; k2p++)
       {
         const float4 f = as_float4(rf[k2p & 3]);
         const float4 c = as_float4(rc[k2p & 3]);
@@ -1032,7 +1046,7 @@ __global__ __launch_bounds__(256, (WD <= 10 ? BIOEM_FAST_WAVES_PER_SIMD : 2)) vo
         xi[FFT_IN(2 * k2p)] = fmaf(c.y, f.x, -(c.x * f.y));
         xr[FFT_IN(2 * k2p + 1)] = fmaf(c.z, f.z, c.w * f.w);
         xi[FFT_IN(2 * k2p + 1)] = fmaf(c.w, f.z, -(c.z * f.w));
-        int tn = k1 * 16 + k2p + 4;
+        int tn = k1 * R2 + k2p + 4;
         unsigned vo = laneoff;
         if (tn >= ttotal)
         { // last steps of this block: run on into the next block (or re-read the last row at the very end)
@@ -1049,7 +1063,7 @@ __global__ __launch_bounds__(256, (WD <= 10 ? BIOEM_FAST_WAVES_PER_SIMD : 2)) vo
 #pragma unroll
       for (int d = -WD; d <= WD; d++)
       {
-        const int pos = FFT_OUT(d & 31);
+        const int pos = FFT_OUT(d & (R - 1));
         const float2 w = wk[d + WD];
         float tr = Tr[d + WD], ti = Ti[d + WD];
         tr = fmaf(xr[pos], w.x, tr);
@@ -1409,6 +1423,15 @@ BatchBuf batch_buf(bioem_hip_ctx *h, int which)
   return b;
 }
 
+// the fast-kernel instantiation for a window half width (10 or 15) and register-FFT length (32, 16, 8)
+typedef void (*fast_kernel_t)(const CompareArgs);
+fast_kernel_t fast_kernel(int winD, int R)
+{
+  if (winD == 10)
+    return R == 32 ? k_compare_fast<10, 32> : R == 16 ? k_compare_fast<10, 16> : k_compare_fast<10, 8>;
+  return R == 32 ? k_compare_fast<15, 32> : R == 16 ? k_compare_fast<15, 16> : k_compare_fast<15, 8>;
+}
+
 int launch_compare_fold(bioem_hip_ctx *h, const BatchBuf &bb, int nOC, int orient0, int conv0, int convPerOrient)
 {
   CompareArgs a;
@@ -1445,10 +1468,7 @@ int launch_compare_fold(bioem_hip_ctx *h, const BatchBuf &bb, int nOC, int orien
   {
     const int NW = 2 * h->winD + 1;
     const size_t lds = fast_lds_bytes(h->N, NW, 4);
-    if (h->winD == 10)
-      hipLaunchKernelGGL(k_compare_fast<10>, grid, dim3(256), lds, h->stream, a);
-    else
-      hipLaunchKernelGGL(k_compare_fast<15>, grid, dim3(256), lds, h->stream, a);
+    hipLaunchKernelGGL(fast_kernel(h->winD, 2 * h->fast), grid, dim3(256), lds, h->stream, a);
   }
   else
   {
@@ -1590,8 +1610,11 @@ int bioem_hip_create(bioem_hip_handle *out, int device, const bioem_hip_param_de
   }
   h->nd = (int) h->disp.size();
 
-  h->fast = (N % 32 == 0 && maxD <= 15 && h->nd <= 31) ? 1 : 0;
-  h->N1 = h->fast ? N / 32 : 0;
+  // fast path: N = N1 * R with R the largest of 32/16/8 dividing N; h->fast holds R/2 (rows per k1 step)
+  h->fast = 0;
+  if (N % 8 == 0 && maxD <= 15 && h->nd <= 31)
+    h->fast = (N % 32 == 0) ? 16 : (N % 16 == 0) ? 8 : 4;
+  h->N1 = h->fast ? N / (2 * h->fast) : 0;
   h->winD = maxD <= 10 ? 10 : 15;
   if (h->fast && h->winD == 10 && h->nd > 21)
     h->winD = 15;
@@ -1604,14 +1627,8 @@ int bioem_hip_create(bioem_hip_handle *out, int device, const bioem_hip_param_de
       return 2;
     }
     if (h->fast)
-    {
-      if (h->winD == 10)
-        HIP_CHECK(h, hipFuncSetAttribute(reinterpret_cast<const void *>(k_compare_fast<10>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
-      else
-        HIP_CHECK(h, hipFuncSetAttribute(reinterpret_cast<const void *>(k_compare_fast<15>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
-    }
+      HIP_CHECK(h, hipFuncSetAttribute(reinterpret_cast<const void *>(fast_kernel(h->winD, 2 * h->fast)),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
     else
     {
       const size_t ldsg = compare_lds_bytes(N, h->H, 2 * maxD + 1, 4);
@@ -2113,7 +2130,7 @@ int bioem_hip_reset_kernel_stats(bioem_hip_handle h)
   return 0;
 }
 
-int bioem_hip_uses_fast_path(bioem_hip_handle h) { return h ? h->fast : 0; }
+int bioem_hip_uses_fast_path(bioem_hip_handle h) { return h && h->fast ? 1 : 0; }
 
 int bioem_hip_r2c(int device, int N, int nImg, const float *in, float *out)
 {

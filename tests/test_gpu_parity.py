@@ -79,7 +79,7 @@ def test_native_path_matches_oracle_and_reference(name):
     case, S = setup_for(name)
     for algo in case["algos"]:
         E = make_engine(S, algo)
-        assert E.fast_path == (S.N % 32 == 0)
+        assert E.fast_path == (S.N % 8 == 0)
         _, pmap, _ = run_native(E, S)
         want, _ = S.run(algo)
         assert_same_posterior(S, pmap, want)
@@ -350,13 +350,12 @@ def test_full_size_sharding_invariance_and_planted_truth(full_workload):
     assert np.mean(full["orient"] == truth) > 0.9
 
 
-def test_full_size_slice_against_oracle(full_workload):
-    """224^2, all 5 CTFs, 6 orientations x 8 particles of the benchmark workload through the CPU oracle."""
+def oracle_on_workload(W, sel, nO, algo=1):
+    """orientations [0, nO) x all CTFs x the particles `sel` of a synthetic workload through the CPU oracle
+    (from the engine's own particle spectra, so that the comparison path alone is under test)."""
     import ctypes as C
-    W = full_workload
     refFFT, sumRef, sumsqRef = W.engine.debug_particles()
-    sel = [0, 1, 2, 3, 500, 501, 998, 999]
-    nsel, nO = len(sel), 6
+    nsel = len(sel)
     pd = orc.ParamDevice()
     for f, _ in orc.ParamDevice._fields_:
         setattr(pd, f, getattr(W.pd, f))
@@ -368,17 +367,49 @@ def test_full_size_slice_against_oracle(full_workload):
     L.orc_init_prob(nsel, W.nOrient, 0, want.ctypes.data, None)
     rsel = np.ascontiguousarray(refFFT[sel])
     ssel, s2sel = np.ascontiguousarray(sumRef[sel]), np.ascontiguousarray(sumsqRef[sel])
-    L.orc_run(C.byref(pd), 1, pts.ctypes.data, len(pts), W.NormDen, W.angles.ctypes.data, W.nOrient, 1, W.px, 0, 0,
-              W.nCTF, W.refCTF.ctypes.data, W.ctfParam.ctypes.data, nsel, rsel.ctypes.data, ssel.ctypes.data,
+    L.orc_run(C.byref(pd), algo, pts.ctypes.data, len(pts), W.NormDen, W.angles.ctypes.data, W.nOrient, 1, W.px, 0,
+              0, W.nCTF, W.refCTF.ctypes.data, W.ctfParam.ctypes.data, nsel, rsel.ctypes.data, ssel.ctypes.data,
               s2sel.ctypes.data, 0, nO, want.ctypes.data, None)
-    _, got = run_workload(W, 0, nO)
-    const = orc.logp_constant(pd)
+    return want, orc.logp_constant(pd)
+
+
+def assert_workload_matches(got, want, const, sel):
     for i, p in enumerate(sel):
         la = np.log(got[p]["Total"]) + got[p]["Constoadd"] + const
         lb = np.log(want[i]["Total"]) + want[i]["Constoadd"] + const
         assert abs(la - lb) <= REL_TOL * abs(lb) and abs(la - lb) <= ABS_TOL
         assert (got[p]["orient"], got[p]["conv"], got[p]["cent_x"], got[p]["cent_y"]) == \
                (want[i]["orient"], want[i]["conv"], want[i]["cent_x"], want[i]["cent_y"])
+
+
+def test_full_size_slice_against_oracle(full_workload):
+    """224^2, all 5 CTFs, 6 orientations x 8 particles of the benchmark workload through the CPU oracle."""
+    W = full_workload
+    sel = [0, 1, 2, 3, 500, 501, 998, 999]
+    nO = 6
+    want, const = oracle_on_workload(W, sel, nO)
+    _, got = run_workload(W, 0, nO)
+    assert_workload_matches(got, want, const, sel)
+
+
+# image sizes by the register-FFT length R the comparison kernel picks (N = N1 * R): 32 | N -> R = 32,
+# 16 | N -> 16, 8 | N -> 8, anything else -> the generic pruned-DFT kernel
+@pytest.mark.parametrize("N,maxD,grid,fast", [(40, 10, 1, 1), (72, 7, 1, 1), (200, 10, 1, 1), (80, 12, 1, 1),
+                                              (48, 15, 1, 1), (96, 10, 2, 1), (160, 10, 1, 1), (256, 10, 1, 1),
+                                              (100, 10, 1, 0), (36, 5, 1, 0)])
+@pytest.mark.parametrize("algo", [1, 2])
+def test_image_sizes_against_oracle(N, maxD, grid, fast, algo):
+    from bioem_amd.synthetic import Workload
+    nP, nO = 6, 9                                   # 9 orientations x 2 CTFs = 18 comparisons: ragged last group
+    W = Workload(N=N, nP=nP, nOrient=nO, nEnv=2, maxD=maxD, grid=grid, algo=algo, npts=300)
+    try:
+        assert W.engine.fast_path is bool(fast)
+        sel = list(range(nP))
+        want, const = oracle_on_workload(W, sel, nO, algo)
+        _, got = run_workload(W, 0, nO)
+        assert_workload_matches(got, want, const, sel)
+    finally:
+        W.engine.close()
 
 
 def _write_mrc(path, data):
