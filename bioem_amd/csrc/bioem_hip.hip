@@ -148,7 +148,7 @@ namespace
 
 // ------------------------------------------------------------------------------------------------
 // layout of a half spectrum used by the comparison kernels
-//   fast   : N = N1*R (R = 32, 16 or 8), kx = N1*k2 + k1  ->  float2 index ((k1*R/2 + (k2>>1))*H + ky)*2 + (k2&1)
+//   fast   : N = N1*R (R = 32, 16, 8, 4 or 2), kx = N1*k2 + k1  ->  float2 index ((k1*R/2 + (k2>>1))*H + ky)*2 + (k2&1)
 //            (lane = ky reads 16 B = two k2 of one k1 -> fully coalesced dwordx4, and the R inputs
 //             of one register FFT arrive as R/2 such loads).  The `fast` argument carries R/2 (0 = generic).
 //   generic: reference layout kx*H + ky
@@ -716,7 +716,7 @@ __host__ __device__ constexpr int bitrevR(int n)
 template <int R>
 __device__ __forceinline__ void fft_inverse_dit(float (&xr)[R], float (&xi)[R])
 {
-  constexpr int LOG2R = (R == 32) ? 5 : (R == 16) ? 4 : 3;
+  constexpr int LOG2R = (R == 32) ? 5 : (R == 16) ? 4 : (R == 8) ? 3 : (R == 4) ? 2 : 1;
 #pragma unroll
   for (int s = 0; s < LOG2R; s++)
   {
@@ -889,7 +889,8 @@ __device__ __forceinline__ void window_accumulate(const float2 *Tl, const float2
 }
 
 // ------------------------------------------------------------------------------------------------
-// fast comparison kernel: N = R*N1 with R = 32, 16 or 8 (the largest of those dividing N), 2*maxD+1 <= 2*WD+1 <= 31.
+// fast comparison kernel: N = R*N1 with R = 32, 16, 8, 4 or 2 (the largest of those dividing N, i.e. any even N),
+// 2*maxD+1 <= 2*WD+1 <= 31.
 // block = 4 waves = 4 consecutive (orientation*CTF) indices of ONE particle (the particle columns are then
 // served to waves 1..3 from L1); blockIdx.x = ocGroup * nMaps + particle, so concurrently resident blocks
 // share the same 4 conv spectra in L2.  Columns are processed in blocks of 64 (lane = column): register
@@ -931,7 +932,8 @@ template <int WD, int R>
 __global__ __launch_bounds__(256, (WD <= 10 ? BIOEM_FAST_WAVES_PER_SIMD : 2)) void k_compare_fast(const CompareArgs a)
 {
   constexpr int NW = 2 * WD + 1;
-  constexpr int R2 = R / 2; // rows (k2 pairs) per k1 step
+  constexpr int R2 = R / 2;            // rows (k2 pairs) per k1 step
+  constexpr int RD = R2 < 4 ? R2 : 4;  // depth of the operand ring
   constexpr int NR = (WD <= 10) ? 7 : 16;
   constexpr int TS = 66; // T row stride in float2 (64 columns + 2 pad: row groups land on different banks)
   extern __shared__ __align__(16) unsigned char smem[];
@@ -1002,11 +1004,11 @@ __global__ __launch_bounds__(256, (WD <= 10 ? BIOEM_FAST_WAVES_PER_SIMD : 2)) vo
   // Addressing: buffer loads -- 128-bit descriptor (SGPRs), one 32-bit lane offset (VGPR), row offset in an SGPR.
   const int ttotal = R2 * N1;
   const unsigned rowbytes = (unsigned) H * 16u;
-  u32x4 rf[4], rc[4];
+  u32x4 rf[RD], rc[RD];
   {
     const unsigned lo0 = (unsigned) (lane < H ? lane : H - 1) * 16u;
 #pragma unroll
-    for (int t = 0; t < 4; t++)
+    for (int t = 0; t < RD; t++)
     {
       rf[t] = __builtin_amdgcn_raw_buffer_load_b128(rsrcF, lo0, (unsigned) t * rowbytes, 0);
       rc[t] = __builtin_amdgcn_raw_buffer_load_b128(rsrcC, lo0, (unsigned) t * rowbytes, 0);
@@ -1039,22 +1041,22 @@ __global__ __launch_bounds__(256, (WD <= 10 ? BIOEM_FAST_WAVES_PER_SIMD : 2)) vo
 #pragma unroll
       for (int k2p = 0; k2p < R2; k2p++)
       {
-        const float4 f = as_float4(rf[k2p & 3]);
-        const float4 c = as_float4(rc[k2p & 3]);
+        const float4 f = as_float4(rf[k2p % RD]);
+        const float4 c = as_float4(rc[k2p % RD]);
         // X = conv * conj(ref)   (bioem.cpp:1452-1455)
         xr[FFT_IN(2 * k2p)] = fmaf(c.x, f.x, c.y * f.y);
         xi[FFT_IN(2 * k2p)] = fmaf(c.y, f.x, -(c.x * f.y));
         xr[FFT_IN(2 * k2p + 1)] = fmaf(c.z, f.z, c.w * f.w);
         xi[FFT_IN(2 * k2p + 1)] = fmaf(c.w, f.z, -(c.z * f.w));
-        int tn = k1 * R2 + k2p + 4;
+        int tn = k1 * R2 + k2p + RD;
         unsigned vo = laneoff;
         if (tn >= ttotal)
         { // last steps of this block: run on into the next block (or re-read the last row at the very end)
           tn = has_next ? tn - ttotal : ttotal - 1;
           vo = has_next ? laneoff_next : laneoff;
         }
-        rf[k2p & 3] = __builtin_amdgcn_raw_buffer_load_b128(rsrcF, vo, (unsigned) tn * rowbytes, 0);
-        rc[k2p & 3] = __builtin_amdgcn_raw_buffer_load_b128(rsrcC, vo, (unsigned) tn * rowbytes, 0);
+        rf[k2p % RD] = __builtin_amdgcn_raw_buffer_load_b128(rsrcF, vo, (unsigned) tn * rowbytes, 0);
+        rc[k2p % RD] = __builtin_amdgcn_raw_buffer_load_b128(rsrcC, vo, (unsigned) tn * rowbytes, 0);
         __builtin_amdgcn_sched_barrier(0);
       }
       FFT_RUN(xr, xi);
@@ -1428,8 +1430,10 @@ typedef void (*fast_kernel_t)(const CompareArgs);
 fast_kernel_t fast_kernel(int winD, int R)
 {
   if (winD == 10)
-    return R == 32 ? k_compare_fast<10, 32> : R == 16 ? k_compare_fast<10, 16> : k_compare_fast<10, 8>;
-  return R == 32 ? k_compare_fast<15, 32> : R == 16 ? k_compare_fast<15, 16> : k_compare_fast<15, 8>;
+    return R == 32 ? k_compare_fast<10, 32> : R == 16 ? k_compare_fast<10, 16> : R == 8 ? k_compare_fast<10, 8>
+           : R == 4 ? k_compare_fast<10, 4> : k_compare_fast<10, 2>;
+  return R == 32 ? k_compare_fast<15, 32> : R == 16 ? k_compare_fast<15, 16> : R == 8 ? k_compare_fast<15, 8>
+         : R == 4 ? k_compare_fast<15, 4> : k_compare_fast<15, 2>;
 }
 
 int launch_compare_fold(bioem_hip_ctx *h, const BatchBuf &bb, int nOC, int orient0, int conv0, int convPerOrient)
@@ -1610,10 +1614,10 @@ int bioem_hip_create(bioem_hip_handle *out, int device, const bioem_hip_param_de
   }
   h->nd = (int) h->disp.size();
 
-  // fast path: N = N1 * R with R the largest of 32/16/8 dividing N; h->fast holds R/2 (rows per k1 step)
+  // fast path: N = N1 * R with R the largest of 32/16/8/4/2 dividing N; h->fast holds R/2 (rows per k1 step)
   h->fast = 0;
-  if (N % 8 == 0 && maxD <= 15 && h->nd <= 31)
-    h->fast = (N % 32 == 0) ? 16 : (N % 16 == 0) ? 8 : 4;
+  if (N % 2 == 0 && N >= 8 && maxD <= 15 && h->nd <= 31)
+    h->fast = (N % 32 == 0) ? 16 : (N % 16 == 0) ? 8 : (N % 8 == 0) ? 4 : (N % 4 == 0) ? 2 : 1;
   h->N1 = h->fast ? N / (2 * h->fast) : 0;
   h->winD = maxD <= 10 ? 10 : 15;
   if (h->fast && h->winD == 10 && h->nd > 21)

@@ -38,7 +38,7 @@ typedef struct
   cpx *tw; /* tw[k] = exp(+2*pi*i*k/n) */
 } fft_plan;
 
-#define MAX_PLANS 16
+#define MAX_PLANS 256
 static fft_plan g_plans[MAX_PLANS];
 static int g_nplans = 0;
 

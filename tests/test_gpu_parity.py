@@ -79,7 +79,7 @@ def test_native_path_matches_oracle_and_reference(name):
     case, S = setup_for(name)
     for algo in case["algos"]:
         E = make_engine(S, algo)
-        assert E.fast_path == (S.N % 8 == 0)
+        assert E.fast_path == (S.N % 2 == 0)
         _, pmap, _ = run_native(E, S)
         want, _ = S.run(algo)
         assert_same_posterior(S, pmap, want)
@@ -392,11 +392,13 @@ def test_full_size_slice_against_oracle(full_workload):
     assert_workload_matches(got, want, const, sel)
 
 
-# image sizes by the register-FFT length R the comparison kernel picks (N = N1 * R): 32 | N -> R = 32,
-# 16 | N -> 16, 8 | N -> 8, anything else -> the generic pruned-DFT kernel
+# image sizes by the register-FFT length R the comparison kernel picks (N = N1 * R, R = the largest of 32, 16, 8, 4,
+# 2 dividing N); odd N and windows beyond +-15 px -> the generic pruned-DFT kernel
 @pytest.mark.parametrize("N,maxD,grid,fast", [(40, 10, 1, 1), (72, 7, 1, 1), (200, 10, 1, 1), (80, 12, 1, 1),
                                               (48, 15, 1, 1), (96, 10, 2, 1), (160, 10, 1, 1), (256, 10, 1, 1),
-                                              (100, 10, 1, 0), (36, 5, 1, 0)])
+                                              (100, 10, 1, 1), (36, 5, 1, 1), (180, 10, 1, 1), (250, 10, 1, 1),
+                                              (90, 9, 3, 1), (10, 2, 1, 1), (75, 10, 1, 0), (64, 16, 1, 0),
+                                              (64, 30, 2, 0)])
 @pytest.mark.parametrize("algo", [1, 2])
 def test_image_sizes_against_oracle(N, maxD, grid, fast, algo):
     from bioem_amd.synthetic import Workload
