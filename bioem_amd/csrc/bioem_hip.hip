@@ -80,6 +80,7 @@ struct bioem_hip_ctx
   int nMaps = 0, nAngles = 0, nCTF = 0, algo = 1;
   int N = 0, H = 0, M = 0;
   int fast = 0, N1 = 0, winD = 0; // winD = template window half width used by the fast kernel
+  bool nyq = false;               // Nyquist column handled outside the 64-column blocks (N/2 a multiple of 64)
   int nd = 0;                     // displacements per axis
   std::vector<int> disp;
   int OB = 0;     // orientations per batch of the native path
@@ -101,6 +102,7 @@ struct bioem_hip_ctx
   int *dDisp = nullptr;
   double2 *dLtab = nullptr;
   float2 *dTwk = nullptr;
+  float *dTnyq = nullptr; // [nMaps][maxOC][2*winD+1] Nyquist-column rows of the current launch (nyq only)
 
   double *dProjReal = nullptr; // [chunkB][N*N]
   double *dTempDen = nullptr;  // [chunkB]
@@ -694,6 +696,9 @@ __device__ __forceinline__ void fft32_inverse(float (&xr)[32], float (&xi)[32])
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float2 as_float2(u32x2 v) { return make_float2(__uint_as_float(v.x), __uint_as_float(v.y)); }
+
 __device__ __forceinline__ float4 as_float4(u32x4 v)
 {
   return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
@@ -769,6 +774,7 @@ struct CompareArgs
   const int *disp;  // nd
   const double2 *ltab; // 64 x {c, -log c}
   const float2 *twk;   // [N1][2*WD+1] recombination twiddles exp(2 pi i d k1 / N), d = -WD..WD
+  float *tnyq;         // [nMaps][ldPart][2*WD+1] Nyquist-column rows (fast path with the Nyquist split only)
   Partial *partials; // [nMaps][ldPart]
   int ldPart;
   int N, H, N1, nd, maxD, nOC, nMaps, algo;
@@ -824,6 +830,11 @@ __device__ __forceinline__ void lsef_push(LseF &L, double lp, int id, float val,
     L.id = id;
     L.val = val;
   }
+  else if (L.m == lpf && id < L.id)
+  { // equal maxima: the first VISITED displacement wins (ids are visiting ranks; a lane may push out of order)
+    L.id = id;
+    L.val = val;
+  }
   L.s += exp_fast_nonpos(lpe - (double) L.m);
 }
 
@@ -855,13 +866,14 @@ __device__ __forceinline__ void lsef_wave_reduce(LseF &L)
 // (already weighted by 1 or 2 per column; zero beyond H).  lane = (iy, group); a group owns `nr` consecutive
 // displacement rows so that each LDS twiddle read E[ky*dy] feeds nr accumulators; T is read two columns
 // at a time (ds_read_b128).  STATIC: nr == NR known at compile time (the +-10 px, grid 1 case).
-template <int NR, bool STATIC>
+// NP = number of column pairs: 32 for a block, 1 for the Nyquist column parked in the pad columns 64/65.
+template <int NR, bool STATIC, int NP, int TS>
 __device__ __forceinline__ void window_accumulate(const float2 *Tl, const float2 *twl, int N, int step, int idx0,
                                                   const int (&rowoff)[NR], int nr, float (&acc)[NR])
 {
   int idx = idx0;
 #pragma unroll 2
-  for (int kp = 0; kp < 32; kp++)
+  for (int kp = 0; kp < NP; kp++)
   {
     const float2 w0 = twl[idx];
     idx += step;
@@ -876,7 +888,8 @@ __device__ __forceinline__ void window_accumulate(const float2 *Tl, const float2
     {
       if (STATIC || r < nr)
       {
-        const float4 t = *reinterpret_cast<const float4 *>(&Tl[rowoff[r] + 2 * kp]);
+        // STATIC: the nr rows of a lane are consecutive (unit grid), so one base + compile-time offsets
+        const float4 t = *reinterpret_cast<const float4 *>(&Tl[(STATIC ? rowoff[0] + r * TS : rowoff[r]) + 2 * kp]);
         float v = acc[r];
         v = fmaf(t.x, w0.x, v);
         v = fmaf(-t.y, w0.y, v);
@@ -928,7 +941,13 @@ __device__ __forceinline__ void window_accumulate(const float2 *Tl, const float2
 #ifndef BIOEM_FAST_WAVES_PER_SIMD
 #define BIOEM_FAST_WAVES_PER_SIMD 3
 #endif
-template <int WD, int R>
+// NYQ (N/2 a multiple of 64, e.g. 128 and 256): the half spectrum has N/2 + 1 columns, one more than fills the
+// 64-lane column blocks, and a whole extra block pass for that single Nyquist column would cost 1/2 (128) or 1/3
+// (256) of the kernel.  Instead k_nyquist_rows (below) forms the 2*WD+1 column-transform outputs of that column
+// for every comparison of the launch by direct summation, and this kernel adds (-1)^dy * Re T[dx][N/2] to its
+// window sums (FFTW c2r convention: weight 1, real part only).  The tail is deliberately tiny: anything larger
+// (an inlined or called summation) pushes the register allocation of the main loop into scratch.
+template <int WD, int R, bool NYQ>
 __global__ __launch_bounds__(256, (WD <= 10 ? BIOEM_FAST_WAVES_PER_SIMD : 2)) void k_compare_fast(const CompareArgs a)
 {
   constexpr int NW = 2 * WD + 1;
@@ -949,8 +968,14 @@ __global__ __launch_bounds__(256, (WD <= 10 ? BIOEM_FAST_WAVES_PER_SIMD : 2)) vo
 
   for (int t = threadIdx.x; t <= N; t += blockDim.x)
     twl[t] = a.tw[t];
+  int *dinv = displ + 32; // visiting rank of the sorted displacement s - maxD (unit grid only)
   for (int t = threadIdx.x; t < a.nd; t += blockDim.x)
-    displ[t] = a.disp[t];
+  {
+    const int dv = a.disp[t];
+    displ[t] = dv;
+    if (dv + a.maxD >= 0 && dv + a.maxD < 32)
+      dinv[dv + a.maxD] = t;
+  }
   for (int t = threadIdx.x; t < 64; t += blockDim.x)
     ltab[t] = a.ltab[t];
   __syncthreads();
@@ -983,20 +1008,26 @@ __global__ __launch_bounds__(256, (WD <= 10 ? BIOEM_FAST_WAVES_PER_SIMD : 2)) vo
   const bool wactive = grp < G;
   const int dy = displ[iy];
   const int step = dy < 0 ? dy + N : dy;
-  const bool is_static = (nr == NR);
+  // static window (the +-10 px, grid 1 case): the displacement set is -maxD..maxD and every lane group owns exactly
+  // NR CONSECUTIVE rows of it in sorted order, whatever the visiting order of the algorithm (ALGO 1 visits
+  // 0..maxD, -maxD..-1); dinv[] translates back to visiting ranks for the arg-max bookkeeping
+  const bool is_static = (nr == NR) && (nd == G * NR) && (nd == 2 * a.maxD + 1);
   float acc[NR];
-  int rowoff[NR];
 #pragma unroll
   for (int r = 0; r < NR; r++)
-  {
     acc[r] = 0.f;
-    int ix = grp * nr + r;
+  // T row (in float2 units) of accumulator r of this lane; idle lanes (grp >= G) read rows 0.. and are dropped
+  // later.  Only the first is kept live across the column loop: the static window uses base + r*TS, the general
+  // one re-reads its rows from the displacement list per block.
+  auto row_of = [&](int r) -> int {
+    int ix = wactive ? grp * nr + r : r;
     if (ix >= nd)
       ix = nd - 1;
-    rowoff[r] = (displ[ix] + WD) * TS;
-  }
+    return (displ[ix] + WD) * TS;
+  };
+  const int rowbase = is_static ? ((wactive ? grp : 0) * NR - a.maxD + WD) * TS : row_of(0);
 
-  const int nblk = (H + 63) / 64;
+  const int nblk = NYQ ? (H - 1) / 64 : (H + 63) / 64;
   // Operand stream (software pipelined across k1 iterations AND column blocks): the (k1, k2-pair) loads of a
   // lane walk t = k1*16 + k2p with a constant stride of H float4; a 4-deep ring of (F, C) pairs keeps 8 dwordx4
   // loads (8 KiB per wave) in flight, re-issued as soon as a slot is consumed.  The ring runs on into the first
@@ -1091,9 +1122,26 @@ __global__ __launch_bounds__(256, (WD <= 10 ? BIOEM_FAST_WAVES_PER_SIMD : 2)) vo
     WAVE_OR_BLOCK_SYNC();
     const int idx0 = (int) (((long long) blk * 64 * step) % N);
     if (is_static)
-      window_accumulate<NR, true>(Tl, twl, N, step, idx0, rowoff, nr, acc);
+    {
+      const int rowoff[NR] = {rowbase};
+      window_accumulate<NR, true, 32, TS>(Tl, twl, N, step, idx0, rowoff, nr, acc);
+    }
     else
-      window_accumulate<NR, false>(Tl, twl, N, step, idx0, rowoff, nr, acc);
+    {
+      int rowoff[NR];
+#pragma unroll
+      for (int r = 0; r < NR; r++)
+        rowoff[r] = row_of(r);
+      window_accumulate<NR, false, 32, TS>(Tl, twl, N, step, idx0, rowoff, nr, acc);
+    }
+  }
+  if (NYQ)
+  {
+    const float *tq = a.tnyq + ((size_t) p * a.ldPart + oc) * NW;
+    const float sg = (dy & 1) ? -1.f : 1.f;
+#pragma unroll
+    for (int r = 0; r < NR; r++)
+      acc[r] = fmaf(sg, tq[is_static ? rowbase / TS + r : row_of(r) / TS], acc[r]);
   }
 
   const bioem_hip_param5 q = a.params[oc];
@@ -1111,9 +1159,10 @@ __global__ __launch_bounds__(256, (WD <= 10 ? BIOEM_FAST_WAVES_PER_SIMD : 2)) vo
 #pragma unroll
   for (int r = 0; r < NR; r++)
   {
-    const int ix = grp * nr + r;
-    if (r < nr && wactive && ix < nd)
+    const int ixs = grp * nr + r; // position in the lane-group order; ix = visiting rank of that displacement
+    if (r < nr && wactive && ixs < nd)
     {
+      const int ix = is_static ? dinv[ixs] : ixs;
       const float cc = acc[r] / nn;
       // bioem_algorithm.h:32-36, float expression in the reference's order
       const float firstele = Np * (sumsqref * q.sumsquareC - cc * cc) + 2 * sumref * q.sumC * cc -
@@ -1133,6 +1182,72 @@ __global__ __launch_bounds__(256, (WD <= 10 ? BIOEM_FAST_WAVES_PER_SIMD : 2)) vo
     r.value = L.val;
     r.pad = 0;
     a.partials[(size_t) p * a.ldPart + oc] = r;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Nyquist-column rows for the fast kernel's NYQ mode: thread = one (particle, orientation*CTF) pair, tile of
+// 16 x 16 pairs per block (each operand line is shared by 16 threads).
+//   tnyq[p][oc][d + WD] = Re sum_kx conv[oc][kx][N/2] * conj(ref[p][kx][N/2]) * w_N^(kx d),  d = -WD..WD
+// The twiddle index is uniform over the block (LDS broadcast reads).
+// ------------------------------------------------------------------------------------------------
+template <int WD>
+__global__ __launch_bounds__(256) void k_nyquist_rows(const CompareArgs a)
+{
+  constexpr int NW = 2 * WD + 1;
+  __shared__ float2 twl[1024];
+  const int N = a.N, H = a.H, N1 = a.N1;
+  const int R2 = N / (2 * N1);
+  for (int t = threadIdx.x; t < N; t += blockDim.x)
+    twl[t] = a.tw[t];
+  __syncthreads();
+  const int tilesOC = (a.nOC + 15) / 16;
+  const int tp = blockIdx.x / tilesOC, to = blockIdx.x - tp * tilesOC;
+  const int p = tp * 16 + (threadIdx.x >> 4), oc = to * 16 + (threadIdx.x & 15);
+  const bool valid = p < a.nMaps && oc < a.nOC;
+  const size_t M = (size_t) N * H;
+  const float2 *F = a.ref + (size_t) (valid ? p : 0) * M;
+  const float2 *C = a.conv + (size_t) (valid ? oc : 0) * M;
+  float acc[NW];
+#pragma unroll
+  for (int d = 0; d < NW; d++)
+    acc[d] = 0.f;
+  for (int k1 = 0; k1 < N1; k1++)
+    for (int k2p = 0; k2p < R2; k2p++)
+    {
+      // the two k2 of a pair are adjacent in the comparison layout: one 16-byte load per operand
+      const size_t li = ((size_t) (k1 * R2 + k2p) * H + N / 2) * 2;
+      const float4 c = *reinterpret_cast<const float4 *>(C + li);
+      const float4 f = *reinterpret_cast<const float4 *>(F + li);
+      // X = conv * conj(ref)   (bioem.cpp:1452-1455)
+      const float x0r = fmaf(c.x, f.x, c.y * f.y), x0i = fmaf(c.y, f.x, -(c.x * f.y));
+      const float x1r = fmaf(c.z, f.z, c.w * f.w), x1i = fmaf(c.w, f.z, -(c.z * f.w));
+      const int kx0 = N1 * (2 * k2p) + k1, kx1 = kx0 + N1;
+      int i0 = (int) (((long long) kx0 * (N - WD)) % N), i1 = (int) (((long long) kx1 * (N - WD)) % N);
+#pragma unroll
+      for (int d = 0; d < NW; d++)
+      {
+        const float2 w0 = twl[i0], w1 = twl[i1];
+        float v = acc[d];
+        v = fmaf(x0r, w0.x, v);
+        v = fmaf(-x0i, w0.y, v);
+        v = fmaf(x1r, w1.x, v);
+        v = fmaf(-x1i, w1.y, v);
+        acc[d] = v;
+        i0 += kx0;
+        if (i0 >= N)
+          i0 -= N;
+        i1 += kx1;
+        if (i1 >= N)
+          i1 -= N;
+      }
+    }
+  if (valid)
+  {
+    float *o = a.tnyq + ((size_t) p * a.ldPart + oc) * NW;
+#pragma unroll
+    for (int d = 0; d < NW; d++)
+      o[d] = acc[d];
   }
 }
 
@@ -1373,7 +1488,7 @@ size_t compare_lds_bytes(int N, int H, int NW, int waves)
 }
 
 size_t fast_lds_bytes(int N, int NW, int waves)
-{ // fast kernel: twiddles + displacement list + log table + per-wave T block [NW][64]
+{ // fast kernel: twiddles + displacement list + log table + per-wave T block [NW][66]
   return (size_t) ((N + 2) & ~1) * 8 + 256 + 1024 + (size_t) waves * NW * 66 * 8;
 }
 
@@ -1427,13 +1542,21 @@ BatchBuf batch_buf(bioem_hip_ctx *h, int which)
 
 // the fast-kernel instantiation for a window half width (10 or 15) and register-FFT length (32, 16, 8)
 typedef void (*fast_kernel_t)(const CompareArgs);
-fast_kernel_t fast_kernel(int winD, int R)
+fast_kernel_t fast_kernel(int winD, int R, bool nyq)
 {
+  if (nyq) // N/2 a multiple of 64 implies R = 32
+    return winD == 10 ? k_compare_fast<10, 32, true> : k_compare_fast<15, 32, true>;
   if (winD == 10)
-    return R == 32 ? k_compare_fast<10, 32> : R == 16 ? k_compare_fast<10, 16> : R == 8 ? k_compare_fast<10, 8>
-           : R == 4 ? k_compare_fast<10, 4> : k_compare_fast<10, 2>;
-  return R == 32 ? k_compare_fast<15, 32> : R == 16 ? k_compare_fast<15, 16> : R == 8 ? k_compare_fast<15, 8>
-         : R == 4 ? k_compare_fast<15, 4> : k_compare_fast<15, 2>;
+    return R == 32   ? k_compare_fast<10, 32, false>
+           : R == 16 ? k_compare_fast<10, 16, false>
+           : R == 8  ? k_compare_fast<10, 8, false>
+           : R == 4  ? k_compare_fast<10, 4, false>
+                     : k_compare_fast<10, 2, false>;
+  return R == 32   ? k_compare_fast<15, 32, false>
+         : R == 16 ? k_compare_fast<15, 16, false>
+         : R == 8  ? k_compare_fast<15, 8, false>
+         : R == 4  ? k_compare_fast<15, 4, false>
+                   : k_compare_fast<15, 2, false>;
 }
 
 int launch_compare_fold(bioem_hip_ctx *h, const BatchBuf &bb, int nOC, int orient0, int conv0, int convPerOrient)
@@ -1448,6 +1571,7 @@ int launch_compare_fold(bioem_hip_ctx *h, const BatchBuf &bb, int nOC, int orien
   a.disp = h->dDisp;
   a.ltab = h->dLtab;
   a.twk = h->dTwk;
+  a.tnyq = h->dTnyq;
   a.partials = h->dPartials;
   a.ldPart = h->maxOC;
   a.N = h->N;
@@ -1472,7 +1596,15 @@ int launch_compare_fold(bioem_hip_ctx *h, const BatchBuf &bb, int nOC, int orien
   {
     const int NW = 2 * h->winD + 1;
     const size_t lds = fast_lds_bytes(h->N, NW, 4);
-    hipLaunchKernelGGL(fast_kernel(h->winD, 2 * h->fast), grid, dim3(256), lds, h->stream, a);
+    if (h->nyq)
+    {
+      const dim3 gridq((unsigned) (((size_t) (h->nMaps + 15) / 16) * ((nOC + 15) / 16)));
+      if (h->winD == 10)
+        hipLaunchKernelGGL(k_nyquist_rows<10>, gridq, dim3(256), 0, h->stream, a);
+      else
+        hipLaunchKernelGGL(k_nyquist_rows<15>, gridq, dim3(256), 0, h->stream, a);
+    }
+    hipLaunchKernelGGL(fast_kernel(h->winD, 2 * h->fast, h->nyq), grid, dim3(256), lds, h->stream, a);
   }
   else
   {
@@ -1619,6 +1751,10 @@ int bioem_hip_create(bioem_hip_handle *out, int device, const bioem_hip_param_de
   if (N % 2 == 0 && N >= 8 && maxD <= 15 && h->nd <= 31)
     h->fast = (N % 32 == 0) ? 16 : (N % 16 == 0) ? 8 : (N % 8 == 0) ? 4 : (N % 4 == 0) ? 2 : 1;
   h->N1 = h->fast ? N / (2 * h->fast) : 0;
+#ifndef BIOEM_NYQUIST_SPLIT
+#define BIOEM_NYQUIST_SPLIT 1
+#endif
+  h->nyq = BIOEM_NYQUIST_SPLIT && h->fast && (N / 2) % 64 == 0;
   h->winD = maxD <= 10 ? 10 : 15;
   if (h->fast && h->winD == 10 && h->nd > 21)
     h->winD = 15;
@@ -1631,7 +1767,7 @@ int bioem_hip_create(bioem_hip_handle *out, int device, const bioem_hip_param_de
       return 2;
     }
     if (h->fast)
-      HIP_CHECK(h, hipFuncSetAttribute(reinterpret_cast<const void *>(fast_kernel(h->winD, 2 * h->fast)),
+      HIP_CHECK(h, hipFuncSetAttribute(reinterpret_cast<const void *>(fast_kernel(h->winD, 2 * h->fast, h->nyq)),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
     else
     {
@@ -1678,6 +1814,8 @@ int bioem_hip_create(bioem_hip_handle *out, int device, const bioem_hip_param_de
   HIP_CHECK(h, hipMalloc(&h->dConv, sizeof(float2) * (size_t) h->maxOC * M));
   HIP_CHECK(h, hipMalloc(&h->dParams, sizeof(bioem_hip_param5) * h->maxOC));
   HIP_CHECK(h, hipMalloc(&h->dPartials, sizeof(Partial) * (size_t) nMaps * h->maxOC));
+  if (h->nyq)
+    HIP_CHECK(h, hipMalloc(&h->dTnyq, sizeof(float) * (size_t) nMaps * h->maxOC * (2 * h->winD + 1)));
   h->probBytes = bioem_hip_prob_size(nMaps, nAngles, pd->writeAngles);
   HIP_CHECK(h, hipMalloc(&h->dProb, h->probBytes));
   {
@@ -1752,7 +1890,8 @@ int bioem_hip_destroy(bioem_hip_handle h)
   void *ptrs[] = {h->dRef,     h->dSumRef,  h->dSumsqRef, h->dCTF,     h->dCtfParam, h->dPts,   h->dAngles,
                   h->dTw,      h->dTwD,     h->dDisp,     h->dLtab,    h->dTwk,     h->dProjReal, h->dTempDen,  h->dRowSpec, h->dSpecRef,
                   h->dScratch, h->dConv,    h->dParams,   h->dPartials, h->dProb,     h->dStage,
-                  h->dProjReal2, h->dTempDen2, h->dRowSpec2, h->dSpecRef2, h->dScratch2, h->dConv2, h->dParams2};
+                  h->dProjReal2, h->dTempDen2, h->dRowSpec2, h->dSpecRef2, h->dScratch2, h->dConv2, h->dParams2,
+                  h->dTnyq};
   for (void *p : ptrs)
     if (p)
       hipFree(p);
