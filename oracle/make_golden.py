@@ -106,7 +106,7 @@ def load_quat576_lines():
 # ----------------------------------------------------------------------------------------------
 def case_table():
     C = {}
-    # G1: 48^2 (not a multiple of 32 -> generic device path), sphere-splat branch, both algos
+    # G1: 48^2 (= 3 * 16), sphere-splat branch, both algos
     C["g1_n48"] = dict(N=48, px=1.77, nP=3, npts=30, extent=24.0, rad=(2.25, 3.4), orient=("list", 40),
                        kw=[("CTF_B_ENV", [50.0, 250.0, 2]), ("CTF_DEFOCUS", [1.0, 3.0, 2]),
                            ("CTF_AMPLITUDE", [0.1, 0.1, 1]), ("DISPLACE_CENTER", [4, 2])],
@@ -192,6 +192,31 @@ def case_table():
                                        ("CTF_DEFOCUS", [1.5, 1.5, 1]), ("CTF_AMPLITUDE", [0.1, 0.1, 1]),
                                        ("DISPLACE_CENTER", [3, 1])],
                                    algos=[1], snr=0.3, maxshift=2, seed=115, particles="mrc")
+    # G16-G20: image sizes that select the other register-FFT lengths of the device kernel (N = N1 * R) and the
+    # Nyquist-column split: 40 = 5*8, 36 = 9*4, 50 = 25*2, 200 = 25*8, 256 = 8*32 with N/2 a multiple of 64
+    C["g16_n40"] = dict(N=40, px=2.6, nP=3, npts=40, extent=28.0, rad=(2.25, 3.4), orient=("list", 12),
+                        kw=[("CTF_B_ENV", [40.0, 200.0, 2]), ("CTF_DEFOCUS", [1.0, 3.0, 2]),
+                            ("CTF_AMPLITUDE", [0.1, 0.1, 1]), ("DISPLACE_CENTER", [6, 1])],
+                        algos=[1, 2], snr=0.2, maxshift=4, seed=116)
+    C["g17_n36"] = dict(N=36, px=2.8, nP=3, npts=40, extent=26.0, rad=(2.25, 3.4), orient=("list", 10),
+                        kw=[("CTF_B_ENV", [40.0, 200.0, 2]), ("CTF_DEFOCUS", [1.0, 3.0, 2]),
+                            ("CTF_AMPLITUDE", [0.1, 0.1, 1]), ("DISPLACE_CENTER", [5, 1])],
+                        algos=[1, 2], snr=0.2, maxshift=3, seed=117)
+    C["g18_n50"] = dict(N=50, px=2.4, nP=3, npts=50, extent=30.0, rad=(2.25, 3.4), orient=("list", 10),
+                        kw=[("CTF_B_ENV", [40.0, 200.0, 2]), ("CTF_DEFOCUS", [1.0, 3.0, 2]),
+                            ("CTF_AMPLITUDE", [0.1, 0.1, 1]), ("DISPLACE_CENTER", [7, 1])],
+                        algos=[1, 2], snr=0.2, maxshift=4, seed=118)
+    C["g19_n200"] = dict(N=200, px=1.77, nP=3, npts=500, extent=58.0, rad=(2.25, 3.4), orient=("list", 6),
+                         kw=[("CTF_B_ENV", [2.0, 300.0, 2]), ("CTF_DEFOCUS", [2.0, 2.0, 1]),
+                             ("CTF_AMPLITUDE", [0.1, 0.1, 1]), ("DISPLACE_CENTER", [10, 1])],
+                         algos=[1], snr=0.05, maxshift=8, seed=119)
+    C["g20_n256"] = dict(N=256, px=1.77, nP=3, npts=600, extent=62.0, rad=(2.25, 3.4), orient=("list", 6),
+                         kw=[("CTF_B_ENV", [2.0, 300.0, 2]), ("CTF_DEFOCUS", [2.0, 2.0, 1]),
+                             ("CTF_AMPLITUDE", [0.1, 0.1, 1]), ("DISPLACE_CENTER", [10, 1])],
+                         algos=[1, 2], snr=0.05, maxshift=8, seed=120)
+    only = os.environ.get("BIOEM_GOLDEN_ONLY")  # e.g. "g16,g17": restrict every stage to cases with these prefixes
+    if only:
+        C = {k: v for k, v in C.items() if any(k.startswith(o + "_") for o in only.split(","))}
     return C
 
 
@@ -297,7 +322,7 @@ def run():
     binary = os.path.join(HERE, "_ref", "bioEM_ref")
     binary_trace = os.path.join(HERE, "_ref", "bioEM_ref_trace")
     ok = True
-    for name in sorted(os.listdir(CASES_DIR)):
+    for name in sorted(case_table()):
         d = os.path.join(CASES_DIR, name)
         inp = np.load(os.path.join(d, "inputs.npz"))
         out = os.path.join(OUT_DIR, name)
@@ -329,7 +354,7 @@ def run():
 
 
 def collect():
-    for name in sorted(os.listdir(CASES_DIR)):
+    for name in sorted(case_table()):
         src_in = os.path.join(CASES_DIR, name)
         src_out = os.path.join(OUT_DIR, name)
         if not os.path.isdir(src_out):
