@@ -60,6 +60,9 @@ def main():
     ap.add_argument("--particles", type=int, default=1000)
     ap.add_argument("--orientations", type=int, default=4608, help="orientations per GPU")
     ap.add_argument("--pixels", type=int, default=224)
+    ap.add_argument("--max-displacement", type=int, default=10, help="DISPLACE_CENTER half width (pixels)")
+    ap.add_argument("--grid", type=int, default=1, help="DISPLACE_CENTER grid spacing")
+    ap.add_argument("--write-angles", action="store_true", help="WRITE_PROB_ANGLES: keep the per-orientation table")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-orientations", type=int, default=16)
     args = ap.parse_args()
@@ -97,12 +100,13 @@ def main():
     # every rank renders the same particle stack (same seeds); orientation seed differs per rank so that the
     # global list is the concatenation of `world` distinct blocks of `orientations` each.
     W = Workload(N=args.pixels, nP=args.particles, nOrient=args.orientations, device=gpu_index,
-                 orient_seed=20260103 + rank)
+                 orient_seed=20260103 + rank, maxD=args.max_displacement, grid=args.grid,
+                 write_angles=args.write_angles)
     E = W.engine
     nMaps = W.nP
 
     def one_step():
-        raw, pmap, _ = new_prob_block(nMaps, W.nOrient, 0)
+        raw, pmap, _ = new_prob_block(nMaps, W.nOrient, int(args.write_angles))
         E.start_run(raw)
         E.project_convolve_compare(0, W.nOrient)
         E.finish_run(raw)

@@ -83,6 +83,7 @@ struct bioem_hip_ctx
   int pchunk = 128;               // particle chunk of the fast kernel's block order (0 = all particles); measured:
                                   // 1 000 particles 6.73 -> 6.56 ms, 10 000 particles (2 GB, beyond the Infinity
                                   // Cache) 78.5 -> 63.2 ms per launch
+  int gs = 1;                     // pixels per window row of the fast kernel (gcd of the displacement offsets)
   bool nyq = false;               // Nyquist column handled outside the 64-column blocks (N/2 a multiple of 64)
   int nd = 0;                     // displacements per axis
   std::vector<int> disp;
@@ -782,6 +783,7 @@ struct CompareArgs
   int ldPart;
   int N, H, N1, nd, maxD, nOC, nMaps, algo;
   int pchunk; // particles per block-order chunk of the fast kernel
+  int gs;     // pixels per window row of the fast kernel (template GS)
   PD pd;
 };
 
@@ -951,7 +953,9 @@ __device__ __forceinline__ void window_accumulate(const float2 *Tl, const float2
 // for every comparison of the launch by direct summation, and this kernel adds (-1)^dy * Re T[dx][N/2] to its
 // window sums (FFTW c2r convention: weight 1, real part only).  The tail is deliberately tiny: anything larger
 // (an inlined or called summation) pushes the register allocation of the main loop into scratch.
-template <int WD, int R, bool NYQ>
+// GS (1..4): row stride of the window in pixels.  T row m (-WD..WD) holds displacement dx = m*GS, so a coarse
+// DISPLACE_CENTER grid whose offsets are all multiples of GS reaches +-15*GS pixels with the same 2*WD+1 rows.
+template <int WD, int R, bool NYQ, int GS>
 __global__ __launch_bounds__(256, (WD <= 10 ? BIOEM_FAST_WAVES_PER_SIMD : 2)) void k_compare_fast(const CompareArgs a)
 {
   constexpr int NW = 2 * WD + 1;
@@ -972,13 +976,15 @@ __global__ __launch_bounds__(256, (WD <= 10 ? BIOEM_FAST_WAVES_PER_SIMD : 2)) vo
 
   for (int t = threadIdx.x; t <= N; t += blockDim.x)
     twl[t] = a.tw[t];
-  int *dinv = displ + 32; // visiting rank of the sorted displacement s - maxD (unit grid only)
+  int *dinv = displ + 32; // visiting rank of window row m (displacement m*GS), index m + mD
+  const int mD = a.maxD / GS;
   for (int t = threadIdx.x; t < a.nd; t += blockDim.x)
   {
     const int dv = a.disp[t];
     displ[t] = dv;
-    if (dv + a.maxD >= 0 && dv + a.maxD < 32)
-      dinv[dv + a.maxD] = t;
+    const int m = dv / GS + mD;
+    if (m >= 0 && m < 32)
+      dinv[m] = t;
   }
   for (int t = threadIdx.x; t < 64; t += blockDim.x)
     ltab[t] = a.ltab[t];
@@ -1028,10 +1034,10 @@ __global__ __launch_bounds__(256, (WD <= 10 ? BIOEM_FAST_WAVES_PER_SIMD : 2)) vo
   const bool wactive = grp < G;
   const int dy = displ[iy];
   const int step = dy < 0 ? dy + N : dy;
-  // static window (the +-10 px, grid 1 case): the displacement set is -maxD..maxD and every lane group owns exactly
+  // static window (the +-10 px, grid 1 case): the window rows are -mD..mD and every lane group owns exactly
   // NR CONSECUTIVE rows of it in sorted order, whatever the visiting order of the algorithm (ALGO 1 visits
   // 0..maxD, -maxD..-1); dinv[] translates back to visiting ranks for the arg-max bookkeeping
-  const bool is_static = (nr == NR) && (nd == G * NR) && (nd == 2 * a.maxD + 1);
+  const bool is_static = (nr == NR) && (nd == G * NR) && (nd == 2 * mD + 1);
   float acc[NR];
 #pragma unroll
   for (int r = 0; r < NR; r++)
@@ -1043,9 +1049,9 @@ __global__ __launch_bounds__(256, (WD <= 10 ? BIOEM_FAST_WAVES_PER_SIMD : 2)) vo
     int ix = wactive ? grp * nr + r : r;
     if (ix >= nd)
       ix = nd - 1;
-    return (displ[ix] + WD) * TS;
+    return (displ[ix] / GS + WD) * TS;
   };
-  const int rowbase = is_static ? ((wactive ? grp : 0) * NR - a.maxD + WD) * TS : row_of(0);
+  const int rowbase = is_static ? ((wactive ? grp : 0) * NR - mD + WD) * TS : row_of(0);
 
   const int nblk = NYQ ? (H - 1) / 64 : (H + 63) / 64;
   // Operand stream (software pipelined across k1 iterations AND column blocks): the (k1, k2-pair) loads of a
@@ -1116,7 +1122,7 @@ __global__ __launch_bounds__(256, (WD <= 10 ? BIOEM_FAST_WAVES_PER_SIMD : 2)) vo
 #pragma unroll
       for (int d = -WD; d <= WD; d++)
       {
-        const int pos = FFT_OUT(d & (R - 1));
+        const int pos = FFT_OUT((d * GS) & (R - 1));
         const float2 w = wk[d + WD];
         float tr = Tr[d + WD], ti = Ti[d + WD];
         tr = fmaf(xr[pos], w.x, tr);
@@ -1208,7 +1214,7 @@ __global__ __launch_bounds__(256, (WD <= 10 ? BIOEM_FAST_WAVES_PER_SIMD : 2)) vo
 // ------------------------------------------------------------------------------------------------
 // Nyquist-column rows for the fast kernel's NYQ mode: thread = one (particle, orientation*CTF) pair, tile of
 // 16 x 16 pairs per block (each operand line is shared by 16 threads).
-//   tnyq[p][oc][d + WD] = Re sum_kx conv[oc][kx][N/2] * conj(ref[p][kx][N/2]) * w_N^(kx d),  d = -WD..WD
+//   tnyq[p][oc][m + WD] = Re sum_kx conv[oc][kx][N/2] * conj(ref[p][kx][N/2]) * w_N^(kx m gs),  m = -WD..WD
 // The twiddle index is uniform over the block (LDS broadcast reads).
 // ------------------------------------------------------------------------------------------------
 template <int WD>
@@ -1243,7 +1249,9 @@ __global__ __launch_bounds__(256) void k_nyquist_rows(const CompareArgs a)
       const float x0r = fmaf(c.x, f.x, c.y * f.y), x0i = fmaf(c.y, f.x, -(c.x * f.y));
       const float x1r = fmaf(c.z, f.z, c.w * f.w), x1i = fmaf(c.w, f.z, -(c.z * f.w));
       const int kx0 = N1 * (2 * k2p) + k1, kx1 = kx0 + N1;
-      int i0 = (int) (((long long) kx0 * (N - WD)) % N), i1 = (int) (((long long) kx1 * (N - WD)) % N);
+      // w^(kx * dx) for dx = -WD*gs, then dx -> dx + gs
+      const int s0 = (int) (((long long) kx0 * a.gs) % N), s1 = (int) (((long long) kx1 * a.gs) % N);
+      int i0 = (int) ((N - ((long long) s0 * WD) % N) % N), i1 = (int) ((N - ((long long) s1 * WD) % N) % N);
 #pragma unroll
       for (int d = 0; d < NW; d++)
       {
@@ -1254,10 +1262,10 @@ __global__ __launch_bounds__(256) void k_nyquist_rows(const CompareArgs a)
         v = fmaf(x1r, w1.x, v);
         v = fmaf(-x1i, w1.y, v);
         acc[d] = v;
-        i0 += kx0;
+        i0 += s0;
         if (i0 >= N)
           i0 -= N;
-        i1 += kx1;
+        i1 += s1;
         if (i1 >= N)
           i1 -= N;
       }
@@ -1562,21 +1570,28 @@ BatchBuf batch_buf(bioem_hip_ctx *h, int which)
 
 // the fast-kernel instantiation for a window half width (10 or 15) and register-FFT length (32, 16, 8)
 typedef void (*fast_kernel_t)(const CompareArgs);
-fast_kernel_t fast_kernel(int winD, int R, bool nyq)
+template <int WD, int GS>
+fast_kernel_t fast_kernel_r(int R, bool nyq)
 {
   if (nyq) // N/2 a multiple of 64 implies R = 32
-    return winD == 10 ? k_compare_fast<10, 32, true> : k_compare_fast<15, 32, true>;
-  if (winD == 10)
-    return R == 32   ? k_compare_fast<10, 32, false>
-           : R == 16 ? k_compare_fast<10, 16, false>
-           : R == 8  ? k_compare_fast<10, 8, false>
-           : R == 4  ? k_compare_fast<10, 4, false>
-                     : k_compare_fast<10, 2, false>;
-  return R == 32   ? k_compare_fast<15, 32, false>
-         : R == 16 ? k_compare_fast<15, 16, false>
-         : R == 8  ? k_compare_fast<15, 8, false>
-         : R == 4  ? k_compare_fast<15, 4, false>
-                   : k_compare_fast<15, 2, false>;
+    return k_compare_fast<WD, 32, true, GS>;
+  return R == 32   ? k_compare_fast<WD, 32, false, GS>
+         : R == 16 ? k_compare_fast<WD, 16, false, GS>
+         : R == 8  ? k_compare_fast<WD, 8, false, GS>
+         : R == 4  ? k_compare_fast<WD, 4, false, GS>
+                   : k_compare_fast<WD, 2, false, GS>;
+}
+
+template <int WD>
+fast_kernel_t fast_kernel_g(int R, bool nyq, int gs)
+{
+  return gs == 1 ? fast_kernel_r<WD, 1>(R, nyq) : gs == 2 ? fast_kernel_r<WD, 2>(R, nyq)
+         : gs == 3 ? fast_kernel_r<WD, 3>(R, nyq) : fast_kernel_r<WD, 4>(R, nyq);
+}
+
+fast_kernel_t fast_kernel(int winD, int R, bool nyq, int gs)
+{
+  return winD == 10 ? fast_kernel_g<10>(R, nyq, gs) : fast_kernel_g<15>(R, nyq, gs);
 }
 
 int launch_compare_fold(bioem_hip_ctx *h, const BatchBuf &bb, int nOC, int orient0, int conv0, int convPerOrient)
@@ -1603,6 +1618,7 @@ int launch_compare_fold(bioem_hip_ctx *h, const BatchBuf &bb, int nOC, int orien
   a.nMaps = h->nMaps;
   a.algo = h->algo;
   a.pd = h->pd;
+  a.gs = h->gs;
   a.pchunk = h->pchunk > 0 ? std::min(h->pchunk, h->nMaps) : h->nMaps;
   const int ocGroups = (nOC + 3) / 4;
   const dim3 grid((unsigned) ((size_t) ocGroups * h->nMaps));
@@ -1625,7 +1641,7 @@ int launch_compare_fold(bioem_hip_ctx *h, const BatchBuf &bb, int nOC, int orien
       else
         hipLaunchKernelGGL(k_nyquist_rows<15>, gridq, dim3(256), 0, h->stream, a);
     }
-    hipLaunchKernelGGL(fast_kernel(h->winD, 2 * h->fast, h->nyq), grid, dim3(256), lds, h->stream, a);
+    hipLaunchKernelGGL(fast_kernel(h->winD, 2 * h->fast, h->nyq, h->gs), grid, dim3(256), lds, h->stream, a);
   }
   else
   {
@@ -1768,15 +1784,32 @@ int bioem_hip_create(bioem_hip_handle *out, int device, const bioem_hip_param_de
   h->nd = (int) h->disp.size();
 
   // fast path: N = N1 * R with R the largest of 32/16/8/4/2 dividing N; h->fast holds R/2 (rows per k1 step)
+  // window rows: row m holds displacement m * gs, gs = gcd of all offsets (1..4 are instantiated), so a coarse grid
+  // with maxD a multiple of the spacing reaches +-15*gs pixels
+  {
+    int gg = 0;
+    for (int d : h->disp)
+    {
+      int x = d < 0 ? -d : d, y = gg;
+      while (y)
+      {
+        const int t = x % y;
+        x = y;
+        y = t;
+      }
+      gg = x;
+    }
+    h->gs = (gg >= 1 && gg <= 4) ? gg : 1;
+  }
   h->fast = 0;
-  if (N % 2 == 0 && N >= 8 && maxD <= 15 && h->nd <= 31)
+  if (N % 2 == 0 && N >= 8 && maxD / h->gs <= 15 && h->nd <= 31)
     h->fast = (N % 32 == 0) ? 16 : (N % 16 == 0) ? 8 : (N % 8 == 0) ? 4 : (N % 4 == 0) ? 2 : 1;
   h->N1 = h->fast ? N / (2 * h->fast) : 0;
 #ifndef BIOEM_NYQUIST_SPLIT
 #define BIOEM_NYQUIST_SPLIT 1
 #endif
   h->nyq = BIOEM_NYQUIST_SPLIT && h->fast && (N / 2) % 64 == 0;
-  h->winD = maxD <= 10 ? 10 : 15;
+  h->winD = maxD / h->gs <= 10 ? 10 : 15;
   if (h->fast && h->winD == 10 && h->nd > 21)
     h->winD = 15;
   // LDS budget check
@@ -1788,7 +1821,7 @@ int bioem_hip_create(bioem_hip_handle *out, int device, const bioem_hip_param_de
       return 2;
     }
     if (h->fast)
-      HIP_CHECK(h, hipFuncSetAttribute(reinterpret_cast<const void *>(fast_kernel(h->winD, 2 * h->fast, h->nyq)),
+      HIP_CHECK(h, hipFuncSetAttribute(reinterpret_cast<const void *>(fast_kernel(h->winD, 2 * h->fast, h->nyq, h->gs)),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
     else
     {
@@ -1889,7 +1922,7 @@ int bioem_hip_create(bioem_hip_handle *out, int device, const bioem_hip_param_de
     for (int k1 = 0; k1 < h->N1; k1++)
       for (int d = -h->winD; d <= h->winD; d++)
       {
-        const double ang = 2.0 * M_PI * (double) (((d * k1) % N + N) % N) / (double) N;
+        const double ang = 2.0 * M_PI * (double) ((((long long) d * h->gs * k1) % N + N) % N) / (double) N;
         twk[(size_t) k1 * NW + d + h->winD] = make_float2((float) cos(ang), (float) sin(ang));
       }
     HIP_CHECK(h, hipMalloc(&h->dTwk, sizeof(float2) * twk.size()));

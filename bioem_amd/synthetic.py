@@ -60,7 +60,7 @@ class Workload:
     """config-2 shaped workload: N^2 maps, nP particles, nOrient orientations, CTF grid, +-maxD displacement."""
 
     def __init__(self, N=224, nP=1000, nOrient=4608, nEnv=5, nDefocus=1, maxD=10, grid=1, px=1.77, npts=2000,
-                 snr=0.05, device=0, algo=1, orient_seed=20260103, render=True):
+                 snr=0.05, device=0, algo=1, orient_seed=20260103, render=True, write_angles=False):
         self.N, self.nP, self.nOrient, self.px = N, nP, nOrient, np.float32(px)
         fac = math.pi * 2.0 * 10000 * float(ELECWAVEL)
         amp = (np.float32(0.1), np.float32(0.1), 1)
@@ -69,6 +69,7 @@ class Workload:
         self.refCTF, self.ctfParam, self.steps = hostlib.ctf_kernels(N, self.px, amp, phase, env)
         self.nCTF = len(self.ctfParam)
         self.pd = make_param_device(N, maxD, grid, nOrient, self.steps, 1, self.px)
+        self.pd.writeAngles = 1 if write_angles else 0
         scale = N * px / (224 * 1.77)
         pts = synth_model(npts, 25.0 * scale, 60.0 * scale)
         self.points, self.NormDen = hostlib.center_model(pts)

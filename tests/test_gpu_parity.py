@@ -394,12 +394,14 @@ def test_full_size_slice_against_oracle(full_workload):
 
 
 # image sizes by the register-FFT length R the comparison kernel picks (N = N1 * R, R = the largest of 32, 16, 8, 4,
-# 2 dividing N); odd N and windows beyond +-15 px -> the generic pruned-DFT kernel
+# 2 dividing N); odd N and windows beyond +-15 rows -> the generic pruned-DFT kernel
 @pytest.mark.parametrize("N,maxD,grid,fast", [(40, 10, 1, 1), (72, 7, 1, 1), (200, 10, 1, 1), (80, 12, 1, 1),
                                               (48, 15, 1, 1), (96, 10, 2, 1), (160, 10, 1, 1), (256, 10, 1, 1),
                                               (100, 10, 1, 1), (36, 5, 1, 1), (180, 10, 1, 1), (250, 10, 1, 1),
                                               (90, 9, 3, 1), (10, 2, 1, 1), (75, 10, 1, 0), (64, 16, 1, 0),
-                                              (64, 30, 2, 0)])
+                                              # coarse grids: window rows step by the gcd of the offsets (1..4)
+                                              (64, 30, 2, 1), (224, 20, 2, 1), (128, 40, 4, 1), (96, 45, 3, 1),
+                                              (64, 9, 2, 1), (100, 25, 5, 0), (64, 31, 2, 0)])
 @pytest.mark.parametrize("algo", [1, 2])
 def test_image_sizes_against_oracle(N, maxD, grid, fast, algo):
     from bioem_amd.synthetic import Workload
