@@ -961,7 +961,7 @@ __global__ __launch_bounds__(256, (WD <= 10 ? BIOEM_FAST_WAVES_PER_SIMD : 2)) vo
   constexpr int NW = 2 * WD + 1;
   constexpr int R2 = R / 2;            // rows (k2 pairs) per k1 step
   constexpr int RD = R2 < 4 ? R2 : 4;  // depth of the operand ring
-  constexpr int NR = (WD <= 10) ? 7 : 16;
+  constexpr int NR = (WD <= 5) ? 3 : (WD <= 10) ? 7 : 16; // accumulators (window rows) per lane
   constexpr int TS = 66; // T row stride in float2 (64 columns + 2 pad: row groups land on different banks)
   extern __shared__ __align__(16) unsigned char smem[];
   const int N = a.N, H = a.H, N1 = a.N1;
@@ -1591,7 +1591,7 @@ fast_kernel_t fast_kernel_g(int R, bool nyq, int gs)
 
 fast_kernel_t fast_kernel(int winD, int R, bool nyq, int gs)
 {
-  return winD == 10 ? fast_kernel_g<10>(R, nyq, gs) : fast_kernel_g<15>(R, nyq, gs);
+  return winD == 5 ? fast_kernel_g<5>(R, nyq, gs) : winD == 10 ? fast_kernel_g<10>(R, nyq, gs) : fast_kernel_g<15>(R, nyq, gs);
 }
 
 int launch_compare_fold(bioem_hip_ctx *h, const BatchBuf &bb, int nOC, int orient0, int conv0, int convPerOrient)
@@ -1636,7 +1636,9 @@ int launch_compare_fold(bioem_hip_ctx *h, const BatchBuf &bb, int nOC, int orien
     if (h->nyq)
     {
       const dim3 gridq((unsigned) (((size_t) (h->nMaps + 15) / 16) * ((nOC + 15) / 16)));
-      if (h->winD == 10)
+      if (h->winD == 5)
+        hipLaunchKernelGGL(k_nyquist_rows<5>, gridq, dim3(256), 0, h->stream, a);
+      else if (h->winD == 10)
         hipLaunchKernelGGL(k_nyquist_rows<10>, gridq, dim3(256), 0, h->stream, a);
       else
         hipLaunchKernelGGL(k_nyquist_rows<15>, gridq, dim3(256), 0, h->stream, a);
@@ -1809,9 +1811,11 @@ int bioem_hip_create(bioem_hip_handle *out, int device, const bioem_hip_param_de
 #define BIOEM_NYQUIST_SPLIT 1
 #endif
   h->nyq = BIOEM_NYQUIST_SPLIT && h->fast && (N / 2) % 64 == 0;
-  h->winD = maxD / h->gs <= 10 ? 10 : 15;
-  if (h->fast && h->winD == 10 && h->nd > 21)
-    h->winD = 15;
+  // window template: 2*winD+1 rows, nd <= rows (ALGO 1 with maxD % grid != 0 visits up to 2*(maxD/grid)+2 offsets)
+  {
+    const int mD = maxD / h->gs;
+    h->winD = (mD <= 5 && h->nd <= 11) ? 5 : (mD <= 10 && h->nd <= 21) ? 10 : 15;
+  }
   // LDS budget check
   {
     const size_t lds = h->fast ? fast_lds_bytes(N, 2 * h->winD + 1, 4) : compare_lds_bytes(N, h->H, 2 * maxD + 1, 4);

@@ -401,7 +401,10 @@ def test_full_size_slice_against_oracle(full_workload):
                                               (90, 9, 3, 1), (10, 2, 1, 1), (75, 10, 1, 0), (64, 16, 1, 0),
                                               # coarse grids: window rows step by the gcd of the offsets (1..4)
                                               (64, 30, 2, 1), (224, 20, 2, 1), (128, 40, 4, 1), (96, 45, 3, 1),
-                                              (64, 9, 2, 1), (100, 25, 5, 0), (64, 31, 2, 0)])
+                                              (64, 9, 2, 1), (100, 25, 5, 0), (64, 31, 2, 0),
+                                              # small windows: the 11-row template (rows <= +-5)
+                                              (224, 5, 1, 1), (128, 10, 2, 1), (64, 0, 1, 1), (96, 20, 4, 1),
+                                              (80, 4, 2, 1), (224, 10, 2, 1)])
 @pytest.mark.parametrize("algo", [1, 2])
 def test_image_sizes_against_oracle(N, maxD, grid, fast, algo):
     from bioem_amd.synthetic import Workload
