@@ -1,0 +1,30 @@
+// compare_args.hpp -- argument block shared by the comparison kernels
+// Part of libbioem_hip.so; included by bioem_hip.hip only (one translation unit, anonymous namespace).
+#ifndef BIOEM_COMPARE_ARGS_HPP
+#define BIOEM_COMPARE_ARGS_HPP
+
+namespace
+{
+
+struct CompareArgs
+{
+  const float2 *ref;  // [nMaps][M] comparison layout
+  const float2 *conv; // [nOC][M]
+  const bioem_hip_param5 *params;
+  const float *sumRef, *sumsqRef;
+  const float2 *tw; // N+1
+  const int *disp;  // nd
+  const double2 *ltab; // 64 x {c, -log c}
+  const float2 *twk;   // [N1][2*WD+1] recombination twiddles exp(2 pi i d k1 / N), d = -WD..WD
+  float *tnyq;         // [nMaps][ldPart][2*WD+1] Nyquist-column rows (fast path with the Nyquist split only)
+  Partial *partials; // [nMaps][ldPart]
+  int ldPart;
+  int N, H, N1, nd, maxD, nOC, nMaps, algo;
+  int pchunk; // particles per block-order chunk of the fast kernel
+  int gs;     // pixels per window row of the fast kernel (template GS)
+  PD pd;
+};
+
+} // namespace
+
+#endif

@@ -1,0 +1,503 @@
+// compare_fast.hpp -- fast comparison kernel (output-pruned 2-D transform fused with the posterior) + Nyquist rows
+// Part of libbioem_hip.so; included by bioem_hip.hip only (one translation unit, anonymous namespace).
+#ifndef BIOEM_COMPARE_FAST_HPP
+#define BIOEM_COMPARE_FAST_HPP
+
+namespace
+{
+
+// ------------------------------------------------------------------------------------------------
+// log of a positive float in double precision, cheap: f = m * 2^e, m in [1,2); c ~ 1/m from a 64-entry
+// table, r = m*c - 1 exactly rounded by one fma (|r| <= 2^-7), log f = e ln2 - log c + log1p(r) with a
+// degree-6 Taylor polynomial (truncation 2^-49/7).  Absolute error ~1e-15, i.e. < 3e-11 after the
+// (3-Np)/2 amplification -- far below the float narrowing the reference applies to logpro.
+// Table entry = {c, -log(c)} in LDS.
+// ------------------------------------------------------------------------------------------------
+__device__ __noinline__ double log_slow_path(float f) { return log((double) f); }
+
+__device__ __forceinline__ double log_of_float(float f, const double2 *ltab)
+{
+  const unsigned int bits = __float_as_uint(f);
+  if (!(f > 1.1754944e-38f) || bits >= 0x7f800000u) // zero, negative, subnormal, inf, nan: exact slow path
+    return log_slow_path(f);
+  const int e = (int) (bits >> 23) - 127;
+  const float m = __uint_as_float((bits & 0x007fffffu) | 0x3f800000u);
+  const double2 t = ltab[(bits >> 17) & 63];
+  const double r = fma((double) m, t.x, -1.0);
+  double p = fma(r, -1.0 / 6.0, 1.0 / 5.0);
+  p = fma(r, p, -1.0 / 4.0);
+  p = fma(r, p, 1.0 / 3.0);
+  p = fma(r, p, -1.0 / 2.0);
+  p = fma(r * r, p, r);
+  return fma((double) e, 0.693147180559945309417232, t.y + p);
+}
+
+// exp of a non-positive double difference through the hardware exp2 (relative error ~2e-7 per term; the
+// terms are summed in double, so log(Total) moves by < 1e-6)
+__device__ __forceinline__ double exp_fast_nonpos(double x) { return (double) __expf((float) x); }
+
+struct LseF
+{
+  float m;
+  double s;
+  int id;
+  float val;
+};
+
+__device__ __forceinline__ void lsef_push(LseF &L, double lp, int id, float val, int algo)
+{
+  const float lpf = (float) lp;
+  const double lpe = (algo == 1) ? (double) lpf : lp;
+  if (L.m < lpf)
+  {
+    L.s = (L.m == -INFINITY) ? 0. : L.s * exp_fast_nonpos((double) L.m - (double) lpf);
+    L.m = lpf;
+    L.id = id;
+    L.val = val;
+  }
+  else if (L.m == lpf && id < L.id)
+  { // equal maxima: the first VISITED displacement wins (ids are visiting ranks; a lane may push out of order)
+    L.id = id;
+    L.val = val;
+  }
+  L.s += exp_fast_nonpos(lpe - (double) L.m);
+}
+
+__device__ __forceinline__ void lsef_wave_reduce(LseF &L)
+{
+  for (int off = 32; off > 0; off >>= 1)
+  {
+    const float m2 = __shfl_xor(L.m, off);
+    const double s2 = __shfl_xor(L.s, off);
+    const int id2 = __shfl_xor(L.id, off);
+    const float v2 = __shfl_xor(L.val, off);
+    if (m2 > L.m || (m2 == L.m && id2 < L.id))
+    {
+      const double sc = (L.m == -INFINITY) ? 0. : L.s * exp_fast_nonpos((double) L.m - (double) m2);
+      L.s = sc + s2;
+      L.m = m2;
+      L.id = id2;
+      L.val = v2;
+    }
+    else
+    {
+      const double sc = (m2 == -INFINITY) ? 0. : s2 * exp_fast_nonpos((double) m2 - (double) L.m);
+      L.s += sc;
+    }
+  }
+}
+
+// Window accumulation over one block of 64 frequency columns held in LDS as Tl[row = dx + WD][64] float2
+// (already weighted by 1 or 2 per column; zero beyond H).  lane = (iy, group); a group owns `nr` consecutive
+// displacement rows so that each LDS twiddle read E[ky*dy] feeds nr accumulators; T is read two columns
+// at a time (ds_read_b128).  STATIC: nr == NR known at compile time (the +-10 px, grid 1 case).
+// NP = number of column pairs: 32 for a block, 1 for the Nyquist column parked in the pad columns 64/65.
+template <int NR, bool STATIC, int NP, int TS>
+__device__ __forceinline__ void window_accumulate(const float2 *Tl, const float2 *twl, int N, int step, int idx0,
+                                                  const int (&rowoff)[NR], int nr, float (&acc)[NR])
+{
+  int idx = idx0;
+#pragma unroll 2
+  for (int kp = 0; kp < NP; kp++)
+  {
+    const float2 w0 = twl[idx];
+    idx += step;
+    if (idx >= N)
+      idx -= N;
+    const float2 w1 = twl[idx];
+    idx += step;
+    if (idx >= N)
+      idx -= N;
+#pragma unroll
+    for (int r = 0; r < NR; r++)
+    {
+      if (STATIC || r < nr)
+      {
+        // STATIC: the nr rows of a lane are consecutive (unit grid), so one base + compile-time offsets
+        const float4 t = *reinterpret_cast<const float4 *>(&Tl[(STATIC ? rowoff[0] + r * TS : rowoff[r]) + 2 * kp]);
+        float v = acc[r];
+        v = fmaf(t.x, w0.x, v);
+        v = fmaf(-t.y, w0.y, v);
+        v = fmaf(t.z, w1.x, v);
+        v = fmaf(-t.w, w1.y, v);
+        acc[r] = v;
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// fast comparison kernel: N = R*N1 with R = 32, 16, 8, 4 or 2 (the largest of those dividing N, i.e. any even N),
+// 2*maxD+1 <= 2*WD+1 <= 31.
+// block = 4 waves = 4 consecutive (orientation*CTF) indices of ONE particle (the particle columns are then
+// served to waves 1..3 from L1); blockIdx.x = ocGroup * nMaps + particle, so concurrently resident blocks
+// share the same 4 conv spectra in L2.  Columns are processed in blocks of 64 (lane = column): register
+// FFTs -> T block in LDS -> window accumulation, so the LDS footprint per wave is (2*WD+1)*64*8 bytes
+// (10.5 KiB for +-10 px => 3 blocks per CU, matching the VGPR-limited 3 waves per SIMD).
+// ------------------------------------------------------------------------------------------------
+// FFT flavour: decimation in time with 6-op butterflies (default) or the decimation-in-frequency original
+// (R = 32 only)
+#ifndef BIOEM_FFT_DIF
+#define BIOEM_FFT_DIF 0
+#endif
+#if BIOEM_FFT_DIF
+#define FFT_IN(k) (k)
+#define FFT_OUT(n) bitrev5(n)
+#define FFT_RUN(xr, xi) fft32_inverse(xr, xi)
+#else
+#define FFT_IN(k) bitrevR<R>(k)
+#define FFT_OUT(n) (n)
+#define FFT_RUN(xr, xi) fft_inverse_dit<R>(xr, xi)
+#endif
+#ifndef BIOEM_BLOCK_BARRIER
+#define BIOEM_BLOCK_BARRIER 1
+#endif
+#if BIOEM_BLOCK_BARRIER
+#define WAVE_OR_BLOCK_SYNC() __syncthreads()
+#else
+#define WAVE_OR_BLOCK_SYNC()                                                                                       \
+  do                                                                                                               \
+  {                                                                                                                \
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");                                                         \
+    __builtin_amdgcn_wave_barrier();                                                                               \
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");                                                         \
+  } while (0)
+#endif
+#ifndef BIOEM_FAST_WAVES_PER_SIMD
+#define BIOEM_FAST_WAVES_PER_SIMD 3
+#endif
+// NYQ (N/2 a multiple of 64, e.g. 128 and 256): the half spectrum has N/2 + 1 columns, one more than fills the
+// 64-lane column blocks, and a whole extra block pass for that single Nyquist column would cost 1/2 (128) or 1/3
+// (256) of the kernel.  Instead k_nyquist_rows (below) forms the 2*WD+1 column-transform outputs of that column
+// for every comparison of the launch by direct summation, and this kernel adds (-1)^dy * Re T[dx][N/2] to its
+// window sums (FFTW c2r convention: weight 1, real part only).  The tail is deliberately tiny: anything larger
+// (an inlined or called summation) pushes the register allocation of the main loop into scratch.
+// GS (1..4): row stride of the window in pixels.  T row m (-WD..WD) holds displacement dx = m*GS, so a coarse
+// DISPLACE_CENTER grid whose offsets are all multiples of GS reaches +-15*GS pixels with the same 2*WD+1 rows.
+template <int WD, int R, bool NYQ, int GS>
+__global__ __launch_bounds__(256, (WD <= 10 ? BIOEM_FAST_WAVES_PER_SIMD : 2)) void k_compare_fast(const CompareArgs a)
+{
+  constexpr int NW = 2 * WD + 1;
+  constexpr int R2 = R / 2;            // rows (k2 pairs) per k1 step
+  constexpr int RD = R2 < 4 ? R2 : 4;  // depth of the operand ring
+  constexpr int NR = (WD <= 5) ? 3 : (WD <= 10) ? 7 : 16; // accumulators (window rows) per lane
+  constexpr int TS = 66; // T row stride in float2 (64 columns + 2 pad: row groups land on different banks)
+  extern __shared__ __align__(16) unsigned char smem[];
+  const int N = a.N, H = a.H, N1 = a.N1;
+  float2 *twl = reinterpret_cast<float2 *>(smem);                            // N+1 (+pad)
+  int *displ = reinterpret_cast<int *>(smem + (size_t) ((N + 2) & ~1) * 8); // nd ints (256 B reserved)
+  double2 *ltab = reinterpret_cast<double2 *>(smem + (size_t) ((N + 2) & ~1) * 8 + 256); // 64 entries
+  float2 *Tall = reinterpret_cast<float2 *>(smem + (size_t) ((N + 2) & ~1) * 8 + 256 + 1024);
+  // wave index made provably uniform (SGPR) so that per-wave base pointers use scalar addressing
+  const int wave = __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6));
+  const int lane = threadIdx.x & 63;
+  float2 *Tl = Tall + (size_t) wave * NW * TS;
+
+  for (int t = threadIdx.x; t <= N; t += blockDim.x)
+    twl[t] = a.tw[t];
+  int *dinv = displ + 32; // visiting rank of window row m (displacement m*GS), index m + mD
+  const int mD = a.maxD / GS;
+  for (int t = threadIdx.x; t < a.nd; t += blockDim.x)
+  {
+    const int dv = a.disp[t];
+    displ[t] = dv;
+    const int m = dv / GS + mD;
+    if (m >= 0 && m < 32)
+      dinv[m] = t;
+  }
+  for (int t = threadIdx.x; t < 64; t += blockDim.x)
+    ltab[t] = a.ltab[t];
+  __syncthreads();
+
+  // block -> (particle, group of 4 orientation*CTF): particle chunks of a.pchunk; inside a chunk the particle index
+  // runs fastest, then the group.  Workgroups go round-robin over the 8 XCDs, so with a chunk size that is a
+  // multiple of 8 a particle always lands on the same XCD, and the ~96 blocks resident per XCD cover
+  // (pchunk/8 particles) x (a few groups): every particle line is then shared through that XCD's L2 by several
+  // groups and every conv line by pchunk/8 particles, instead of each particle line being fetched from Infinity
+  // Cache/HBM once per group.
+  int p, ocg;
+  {
+    const int ocGroups = (a.nOC + 3) >> 2;
+    const int per = a.pchunk * ocGroups;
+    int c = blockIdx.x / per;
+    const int nch = (a.nMaps + a.pchunk - 1) / a.pchunk;
+    c = min(c, nch - 1);
+    const int rem = blockIdx.x - c * per;
+    const int pc = min(a.pchunk, a.nMaps - c * a.pchunk);
+    ocg = rem / pc;
+    p = c * a.pchunk + (rem - ocg * pc);
+  }
+  const int oc_raw = ocg * 4 + wave;
+  const bool oc_valid = oc_raw < a.nOC;
+  const int oc = oc_valid ? oc_raw : a.nOC - 1;
+  const size_t M = (size_t) N * H;
+  // buffer descriptors built from wave-uniform values only (blockIdx / readfirstlane'd wave id)
+  // timing-only ablation builds (never shipped): a zero-record descriptor drops the loads of one operand while
+  // the instruction stream and waits stay (cdna_hip_programming.md, profiling: pricing one buffer's traffic)
+#ifndef BIOEM_ABLATE_F
+#define BIOEM_ABLATE_F 0
+#endif
+#ifndef BIOEM_ABLATE_C
+#define BIOEM_ABLATE_C 0
+#endif
+  const auto rsrcF = __builtin_amdgcn_make_buffer_rsrc(const_cast<float2 *>(a.ref + (size_t) p * M), 0,
+                                                       BIOEM_ABLATE_F ? 0 : (int) (M * sizeof(float2)), 0x00020000);
+  const auto rsrcC = __builtin_amdgcn_make_buffer_rsrc(const_cast<float2 *>(a.conv + (size_t) oc * M), 0,
+                                                       BIOEM_ABLATE_C ? 0 : (int) (M * sizeof(float2)), 0x00020000);
+
+  // window lanes
+  const int nd = a.nd;
+  const int G = 64 / nd;
+  const int nr = (nd + G - 1) / G;
+  const int iy = lane % nd, grp = lane / nd;
+  const bool wactive = grp < G;
+  const int dy = displ[iy];
+  const int step = dy < 0 ? dy + N : dy;
+  // static window (the +-10 px, grid 1 case): the window rows are -mD..mD and every lane group owns exactly
+  // NR CONSECUTIVE rows of it in sorted order, whatever the visiting order of the algorithm (ALGO 1 visits
+  // 0..maxD, -maxD..-1); dinv[] translates back to visiting ranks for the arg-max bookkeeping
+  const bool is_static = (nr == NR) && (nd == G * NR) && (nd == 2 * mD + 1);
+  float acc[NR];
+#pragma unroll
+  for (int r = 0; r < NR; r++)
+    acc[r] = 0.f;
+  // T row (in float2 units) of accumulator r of this lane; idle lanes (grp >= G) read rows 0.. and are dropped
+  // later.  Only the first is kept live across the column loop: the static window uses base + r*TS, the general
+  // one re-reads its rows from the displacement list per block.
+  auto row_of = [&](int r) -> int {
+    int ix = wactive ? grp * nr + r : r;
+    if (ix >= nd)
+      ix = nd - 1;
+    return (displ[ix] / GS + WD) * TS;
+  };
+  const int rowbase = is_static ? ((wactive ? grp : 0) * NR - mD + WD) * TS : row_of(0);
+
+  const int nblk = NYQ ? (H - 1) / 64 : (H + 63) / 64;
+  // Operand stream (software pipelined across k1 iterations AND column blocks): the (k1, k2-pair) loads of a
+  // lane walk t = k1*16 + k2p with a constant stride of H float4; a 4-deep ring of (F, C) pairs keeps 8 dwordx4
+  // loads (8 KiB per wave) in flight, re-issued as soon as a slot is consumed.  The ring runs on into the first
+  // rows of the NEXT column block, so those loads fly during the T exchange / window phase of this block.
+  // Addressing: buffer loads -- 128-bit descriptor (SGPRs), one 32-bit lane offset (VGPR), row offset in an SGPR.
+  const int ttotal = R2 * N1;
+  const unsigned rowbytes = (unsigned) H * 16u;
+  u32x4 rf[RD], rc[RD];
+  {
+    const unsigned lo0 = (unsigned) (lane < H ? lane : H - 1) * 16u;
+#pragma unroll
+    for (int t = 0; t < RD; t++)
+    {
+      rf[t] = __builtin_amdgcn_raw_buffer_load_b128(rsrcF, lo0, (unsigned) t * rowbytes, 0);
+      rc[t] = __builtin_amdgcn_raw_buffer_load_b128(rsrcC, lo0, (unsigned) t * rowbytes, 0);
+    }
+  }
+  for (int blk = 0; blk < nblk; blk++)
+  {
+    const int ky = blk * 64 + lane;
+    const int kyc = ky < H ? ky : H - 1;
+    const unsigned laneoff = (unsigned) kyc * 16u;
+    const int kyn = ky + 64 < H ? ky + 64 : H - 1;
+    const unsigned laneoff_next = (unsigned) kyn * 16u;
+    const bool has_next = blk + 1 < nblk;
+    float Tr[NW], Ti[NW];
+#pragma unroll
+    for (int d = 0; d < NW; d++)
+    {
+      Tr[d] = 0.f;
+      Ti[d] = 0.f;
+    }
+    for (int k1 = 0; k1 < N1; k1++)
+    {
+      float xr[R], xi[R];
+      // the 2*WD+1 recombination twiddles of this k1 are contiguous: a few wide scalar loads, issued early
+      float2 wk[NW];
+      const float2 *twk = a.twk + (size_t) k1 * NW;
+#pragma unroll
+      for (int d = 0; d < NW; d++)
+        wk[d] = twk[d];
+#pragma unroll
+      for (int k2p = 0; k2p < R2; k2p++)
+      {
+        const float4 f = as_float4(rf[k2p % RD]);
+        const float4 c = as_float4(rc[k2p % RD]);
+        // X = conv * conj(ref)   (bioem.cpp:1452-1455)
+        xr[FFT_IN(2 * k2p)] = fmaf(c.x, f.x, c.y * f.y);
+        xi[FFT_IN(2 * k2p)] = fmaf(c.y, f.x, -(c.x * f.y));
+        xr[FFT_IN(2 * k2p + 1)] = fmaf(c.z, f.z, c.w * f.w);
+        xi[FFT_IN(2 * k2p + 1)] = fmaf(c.w, f.z, -(c.z * f.w));
+        int tn = k1 * R2 + k2p + RD;
+        unsigned vo = laneoff;
+        if (tn >= ttotal)
+        { // last steps of this block: run on into the next block (or re-read the last row at the very end)
+          tn = has_next ? tn - ttotal : ttotal - 1;
+          vo = has_next ? laneoff_next : laneoff;
+        }
+        rf[k2p % RD] = __builtin_amdgcn_raw_buffer_load_b128(rsrcF, vo, (unsigned) tn * rowbytes, 0);
+        rc[k2p % RD] = __builtin_amdgcn_raw_buffer_load_b128(rsrcC, vo, (unsigned) tn * rowbytes, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      FFT_RUN(xr, xi);
+      // recombination of the N1 sub-transforms for the displacement window only:
+      //   T[dx] += w_N^(dx*k1) * y_k1[dx mod 32]
+#pragma unroll
+      for (int d = -WD; d <= WD; d++)
+      {
+        const int pos = FFT_OUT((d * GS) & (R - 1));
+        const float2 w = wk[d + WD];
+        float tr = Tr[d + WD], ti = Ti[d + WD];
+        tr = fmaf(xr[pos], w.x, tr);
+        tr = fmaf(-xi[pos], w.y, tr);
+        ti = fmaf(xr[pos], w.y, ti);
+        ti = fmaf(xi[pos], w.x, ti);
+        Tr[d + WD] = tr;
+        Ti[d + WD] = ti;
+      }
+    }
+    // FFTW c2r convention: columns 0 and N/2 enter once (real part only after the ky pass), others twice
+    float wgt = 2.f;
+    if (ky == 0 || (((N & 1) == 0) && ky == N / 2))
+      wgt = 1.f;
+    if (ky >= H)
+      wgt = 0.f;
+    // T block of THIS wave only: LDS operations of one wave execute in order, so a wave-level fence (no
+    // s_barrier) is enough; BIOEM_BLOCK_BARRIER=1 restores block barriers (keeps the 4 waves in lock-step)
+    WAVE_OR_BLOCK_SYNC(); // previous block's window reads are done
+#pragma unroll
+    for (int d = 0; d < NW; d++)
+      Tl[d * TS + lane] = make_float2(Tr[d] * wgt, Ti[d] * wgt);
+    WAVE_OR_BLOCK_SYNC();
+    const int idx0 = (int) (((long long) blk * 64 * step) % N);
+    if (is_static)
+    {
+      const int rowoff[NR] = {rowbase};
+      window_accumulate<NR, true, 32, TS>(Tl, twl, N, step, idx0, rowoff, nr, acc);
+    }
+    else
+    {
+      int rowoff[NR];
+#pragma unroll
+      for (int r = 0; r < NR; r++)
+        rowoff[r] = row_of(r);
+      window_accumulate<NR, false, 32, TS>(Tl, twl, N, step, idx0, rowoff, nr, acc);
+    }
+  }
+  if (NYQ)
+  {
+    const float *tq = a.tnyq + ((size_t) p * a.ldPart + oc) * NW;
+    const float sg = (dy & 1) ? -1.f : 1.f;
+#pragma unroll
+    for (int r = 0; r < NR; r++)
+      acc[r] = fmaf(sg, tq[is_static ? rowbase / TS + r : row_of(r) / TS], acc[r]);
+  }
+
+  const bioem_hip_param5 q = a.params[oc];
+  const float sumref = a.sumRef[p], sumsqref = a.sumsqRef[p];
+  double t2, prior;
+  logpro_consts(a.pd, q, t2, prior);
+  const float Np = a.pd.Ntotpi;
+  const double A = (double) (3 - Np) * 0.5;
+  const float nn = (float) (N * N);
+  LseF L;
+  L.m = -INFINITY;
+  L.s = 0.;
+  L.id = 0x7fffffff;
+  L.val = 0.f;
+#pragma unroll
+  for (int r = 0; r < NR; r++)
+  {
+    const int ixs = grp * nr + r; // position in the lane-group order; ix = visiting rank of that displacement
+    if (r < nr && wactive && ixs < nd)
+    {
+      const int ix = is_static ? dinv[ixs] : ixs;
+      const float cc = acc[r] / nn;
+      // bioem_algorithm.h:32-36, float expression in the reference's order
+      const float firstele = Np * (sumsqref * q.sumsquareC - cc * cc) + 2 * sumref * q.sumC * cc -
+                             sumsqref * q.sumC * q.sumC - sumref * sumref * q.sumsquareC;
+      double lp = A * log_of_float(firstele, ltab) + t2;
+      lp -= prior;
+      lsef_push(L, lp, ix * nd + iy, cc, a.algo);
+    }
+  }
+  lsef_wave_reduce(L);
+  if (lane == 0 && oc_valid)
+  {
+    Partial r;
+    r.sumExp = L.s;
+    r.best = L.m;
+    r.id = L.id;
+    r.value = L.val;
+    r.pad = 0;
+    a.partials[(size_t) p * a.ldPart + oc] = r;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Nyquist-column rows for the fast kernel's NYQ mode: thread = one (particle, orientation*CTF) pair, tile of
+// 16 x 16 pairs per block (each operand line is shared by 16 threads).
+//   tnyq[p][oc][m + WD] = Re sum_kx conv[oc][kx][N/2] * conj(ref[p][kx][N/2]) * w_N^(kx m gs),  m = -WD..WD
+// The twiddle index is uniform over the block (LDS broadcast reads).
+// ------------------------------------------------------------------------------------------------
+template <int WD>
+__global__ __launch_bounds__(256) void k_nyquist_rows(const CompareArgs a)
+{
+  constexpr int NW = 2 * WD + 1;
+  __shared__ float2 twl[1024];
+  const int N = a.N, H = a.H, N1 = a.N1;
+  const int R2 = N / (2 * N1);
+  for (int t = threadIdx.x; t < N; t += blockDim.x)
+    twl[t] = a.tw[t];
+  __syncthreads();
+  const int tilesOC = (a.nOC + 15) / 16;
+  const int tp = blockIdx.x / tilesOC, to = blockIdx.x - tp * tilesOC;
+  const int p = tp * 16 + (threadIdx.x >> 4), oc = to * 16 + (threadIdx.x & 15);
+  const bool valid = p < a.nMaps && oc < a.nOC;
+  const size_t M = (size_t) N * H;
+  const float2 *F = a.ref + (size_t) (valid ? p : 0) * M;
+  const float2 *C = a.conv + (size_t) (valid ? oc : 0) * M;
+  float acc[NW];
+#pragma unroll
+  for (int d = 0; d < NW; d++)
+    acc[d] = 0.f;
+  for (int k1 = 0; k1 < N1; k1++)
+    for (int k2p = 0; k2p < R2; k2p++)
+    {
+      // the two k2 of a pair are adjacent in the comparison layout: one 16-byte load per operand
+      const size_t li = ((size_t) (k1 * R2 + k2p) * H + N / 2) * 2;
+      const float4 c = *reinterpret_cast<const float4 *>(C + li);
+      const float4 f = *reinterpret_cast<const float4 *>(F + li);
+      // X = conv * conj(ref)   (bioem.cpp:1452-1455)
+      const float x0r = fmaf(c.x, f.x, c.y * f.y), x0i = fmaf(c.y, f.x, -(c.x * f.y));
+      const float x1r = fmaf(c.z, f.z, c.w * f.w), x1i = fmaf(c.w, f.z, -(c.z * f.w));
+      const int kx0 = N1 * (2 * k2p) + k1, kx1 = kx0 + N1;
+      // w^(kx * dx) for dx = -WD*gs, then dx -> dx + gs
+      const int s0 = (int) (((long long) kx0 * a.gs) % N), s1 = (int) (((long long) kx1 * a.gs) % N);
+      int i0 = (int) ((N - ((long long) s0 * WD) % N) % N), i1 = (int) ((N - ((long long) s1 * WD) % N) % N);
+#pragma unroll
+      for (int d = 0; d < NW; d++)
+      {
+        const float2 w0 = twl[i0], w1 = twl[i1];
+        float v = acc[d];
+        v = fmaf(x0r, w0.x, v);
+        v = fmaf(-x0i, w0.y, v);
+        v = fmaf(x1r, w1.x, v);
+        v = fmaf(-x1i, w1.y, v);
+        acc[d] = v;
+        i0 += s0;
+        if (i0 >= N)
+          i0 -= N;
+        i1 += s1;
+        if (i1 >= N)
+          i1 -= N;
+      }
+    }
+  if (valid)
+  {
+    float *o = a.tnyq + ((size_t) p * a.ldPart + oc) * NW;
+#pragma unroll
+    for (int d = 0; d < NW; d++)
+      o[d] = acc[d];
+  }
+}
+
+} // namespace
+
+#endif
