@@ -145,9 +145,16 @@ __device__ __forceinline__ void window_accumulate(const float2 *Tl, const float2
 #define FFT_OUT(n) bitrev5(n)
 #define FFT_RUN(xr, xi) fft32_inverse(xr, xi)
 #else
-#define FFT_IN(k) bitrevR<R>(k)
+#define FFT_IN(k) (is_pow2(R) ? bitrevR<R>(k) : DIGITREV<R>.pos[k])
 #define FFT_OUT(n) (n)
-#define FFT_RUN(xr, xi) fft_inverse_dit<R>(xr, xi)
+#define FFT_RUN(xr, xi)                                                                                            \
+  do                                                                                                               \
+  {                                                                                                                \
+    if constexpr (is_pow2(R))                                                                                      \
+      fft_inverse_dit<R>(xr, xi);                                                                                  \
+    else                                                                                                           \
+      fft_inverse_mixed<R>(xr, xi);                                                                                \
+  } while (0)
 #endif
 #ifndef BIOEM_BLOCK_BARRIER
 #define BIOEM_BLOCK_BARRIER 1
@@ -179,7 +186,8 @@ __global__ __launch_bounds__(256, (WD <= 10 ? BIOEM_FAST_WAVES_PER_SIMD : 2)) vo
 {
   constexpr int NW = 2 * WD + 1;
   constexpr int R2 = R / 2;            // rows (k2 pairs) per k1 step
-  constexpr int RD = R2 < 4 ? R2 : 4;  // depth of the operand ring
+  // depth of the operand ring: must divide R2 so that a ring slot is a compile-time function of the k2 pair
+  constexpr int RD = (R2 % 4 == 0) ? 4 : (R2 % 5 == 0) ? 5 : (R2 % 3 == 0) ? 3 : (R2 % 2 == 0) ? 2 : 1;
   constexpr int NR = (WD <= 5) ? 3 : (WD <= 10) ? 7 : 16; // accumulators (window rows) per lane
   constexpr int TS = 66; // T row stride in float2 (64 columns + 2 pad: row groups land on different banks)
   extern __shared__ __align__(16) unsigned char smem[];
@@ -341,7 +349,7 @@ __global__ __launch_bounds__(256, (WD <= 10 ? BIOEM_FAST_WAVES_PER_SIMD : 2)) vo
 #pragma unroll
       for (int d = -WD; d <= WD; d++)
       {
-        const int pos = FFT_OUT((d * GS) & (R - 1));
+        const int pos = FFT_OUT((((d * GS) % R) + R) % R);
         const float2 w = wk[d + WD];
         float tr = Tr[d + WD], ti = Ti[d + WD];
         tr = fmaf(xr[pos], w.x, tr);

@@ -393,8 +393,9 @@ def test_full_size_slice_against_oracle(full_workload):
     assert_workload_matches(got, want, const, sel)
 
 
-# image sizes by the register-FFT length R the comparison kernel picks (N = N1 * R, R = the largest of 32, 16, 8, 4,
-# 2 dividing N); odd N and windows beyond +-15 rows -> the generic pruned-DFT kernel
+# image sizes by the register-FFT length R the comparison kernel picks (N = N1 * R: the power-of-two part of N up to
+# 32, or a 2/3/5-smooth divisor up to 30 when that part is 2 or 4); odd N and windows beyond +-15 rows -> the
+# generic pruned-DFT kernel
 @pytest.mark.parametrize("N,maxD,grid,fast", [(40, 10, 1, 1), (72, 7, 1, 1), (200, 10, 1, 1), (80, 12, 1, 1),
                                               (48, 15, 1, 1), (96, 10, 2, 1), (160, 10, 1, 1), (256, 10, 1, 1),
                                               (100, 10, 1, 1), (36, 5, 1, 1), (180, 10, 1, 1), (250, 10, 1, 1),
@@ -402,6 +403,10 @@ def test_full_size_slice_against_oracle(full_workload):
                                               # coarse grids: window rows step by the gcd of the offsets (1..4)
                                               (64, 30, 2, 1), (224, 20, 2, 1), (128, 40, 4, 1), (96, 45, 3, 1),
                                               (64, 9, 2, 1), (100, 25, 5, 0), (64, 31, 2, 0),
+                                              # register-FFT lengths: 56 -> 8, 44 -> 4, 34 -> 2 (radix 2); mixed radix
+                                              # 42 -> 6, 50 -> 10, 84 -> 12, 36 -> 18, 100 -> 20, 90/180/150 -> 30
+                                              (56, 10, 1, 1), (44, 10, 1, 1), (34, 8, 1, 1), (42, 10, 1, 1),
+                                              (84, 10, 1, 1), (120, 10, 1, 1), (150, 10, 1, 1), (300, 10, 1, 1),
                                               # small windows: the 11-row template (rows <= +-5)
                                               (224, 5, 1, 1), (128, 10, 2, 1), (64, 0, 1, 1), (96, 20, 4, 1),
                                               (80, 4, 2, 1), (224, 10, 2, 1)])
