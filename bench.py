@@ -60,6 +60,8 @@ def main():
     ap.add_argument("--particles", type=int, default=1000)
     ap.add_argument("--orientations", type=int, default=4608, help="orientations per GPU")
     ap.add_argument("--pixels", type=int, default=224)
+    ap.add_argument("--envelopes", type=int, default=5, help="CTF_B_ENV grid points")
+    ap.add_argument("--defocus", type=int, default=1, help="CTF_DEFOCUS grid points (config 3: 2 x 5 envelopes = 10 CTFs)")
     ap.add_argument("--max-displacement", type=int, default=10, help="DISPLACE_CENTER half width (pixels)")
     ap.add_argument("--grid", type=int, default=1, help="DISPLACE_CENTER grid spacing")
     ap.add_argument("--write-angles", action="store_true", help="WRITE_PROB_ANGLES: keep the per-orientation table")
@@ -100,7 +102,7 @@ def main():
     # every rank renders the same particle stack (same seeds); orientation seed differs per rank so that the
     # global list is the concatenation of `world` distinct blocks of `orientations` each.
     W = Workload(N=args.pixels, nP=args.particles, nOrient=args.orientations, device=gpu_index,
-                 orient_seed=20260103 + rank, maxD=args.max_displacement, grid=args.grid,
+                 orient_seed=20260103 + rank, nEnv=args.envelopes, nDefocus=args.defocus, maxD=args.max_displacement, grid=args.grid,
                  write_angles=args.write_angles)
     E = W.engine
     nMaps = W.nP
@@ -135,6 +137,9 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
+    shape = (W.N, W.nP, W.nOrient, W.nCTF, args.max_displacement, args.grid)
+    workload_name = {(224, 1000, 4608, 5, 10, 1): "BASELINE config 2 per GPU",
+                     (224, 10000, 4608, 10, 10, 1): "BASELINE config 3, one GPU's share of 8"}.get(shape, "custom")
     total_comparisons = world * W.comparisons_per_pass * args.steps
     value = total_comparisons / dt
     b_alg = 8 * W.N * (W.N // 2 + 1)  # bytes: one read of the particle half-spectrum per comparison
@@ -153,8 +158,9 @@ def main():
         "vs_baseline": None,
         "dtype": "f32",
         "data": "synthetic",
-        "config": {"workload": "BASELINE config 2 per GPU: %d^2 maps, %d particles, %d orientations/GPU, %d CTF "
-                               "envelopes, +-10 px (441 displacements)" % (W.N, W.nP, W.nOrient, W.nCTF),
+        "config": {"workload": "%s: %d^2 maps, %d particles, %d orientations/GPU, %d CTFs, +-%d px grid %d (%d "
+                               "displacements)" % (workload_name, W.N, W.nP, W.nOrient, W.nCTF,
+                                                   args.max_displacement, args.grid, int(W.pd.NtotDisp)),
                    "pixels": W.N, "particles": W.nP, "orientations_per_gpu": W.nOrient, "ctf": W.nCTF,
                    "displacements": int(W.pd.NtotDisp), "orientation_list": "seeded uniform random quaternions",
                    "fast_path": bool(E.fast_path), "parallelism": "orientation blocks x%d, RCCL log-sum-exp merge"
