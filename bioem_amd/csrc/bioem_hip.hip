@@ -495,7 +495,7 @@ int bioem_hip_create(bioem_hip_handle *out, int device, const bioem_hip_param_de
 #ifndef BIOEM_NYQUIST_SPLIT
 #define BIOEM_NYQUIST_SPLIT 1
 #endif
-  h->nyq = BIOEM_NYQUIST_SPLIT && h->fast && (N / 2) % 64 == 0;
+  h->nyq = BIOEM_NYQUIST_SPLIT && h->fast && (N / 2) % 64 == 0 && N <= 1024; // k_nyquist_rows: twiddles of N <= 1024 in LDS
   // window template: 2*winD+1 rows, nd <= rows (ALGO 1 with maxD % grid != 0 visits up to 2*(maxD/grid)+2 offsets)
   {
     const int mD = maxD / h->gs;
