@@ -18,7 +18,7 @@
 //                        k_nyquist_rows   the Nyquist column of 128^2 / 256^2 by direct summation
 //   compare_generic.hpp  k_compare_generic  same maths for odd N / very wide windows (direct pruned DFT)
 //   posterior.hpp        calc_logpro / calProb semantics (bioem_algorithm.h:18-142)
-//   fold_kernels.hpp     k_fold, k_fold_wave: fold the per-comparison partials into the probability block in the
+//   fold_kernels.hpp     k_fold_wave, k_fold_angles (k_fold: serial variant): fold the per-comparison partials into the probability block in the
 //                          reference's (orientation, CTF) order (bioem_algorithm.h:96-123, bioem.cpp:1527-1600)
 //   this file            device context, launch logic, the C ABI
 //
@@ -328,13 +328,22 @@ int launch_compare_fold(bioem_hip_ctx *h, const BatchBuf &bb, int nOC, int orien
   h->comparisons += (long long) nOC * h->nMaps;
   bioem_hip_prob_map *pmap = reinterpret_cast<bioem_hip_prob_map *>(h->dProb);
   bioem_hip_prob_angle *pang = reinterpret_cast<bioem_hip_prob_angle *>(h->dProb + sizeof(bioem_hip_prob_map) * h->nMaps);
-  if (h->pd.writeAngles)
+  static const bool serialFold = getenv("BIOEM_SERIAL_FOLD") != nullptr; // debugging: the one-thread-per-particle fold
+  if (serialFold)
     hipLaunchKernelGGL(k_fold, dim3((h->nMaps + 127) / 128), dim3(128), 0, h->stream, h->dPartials, h->maxOC, nOC,
                        h->nMaps, bb.params, h->dSumRef, h->dDisp, h->nd, h->pd, orient0, conv0, convPerOrient, pmap,
                        pang);
   else
+  {
+    if (h->pd.writeAngles)
+    {
+      const long long nt = (long long) ((nOC + convPerOrient - 1) / convPerOrient) * h->nMaps;
+      hipLaunchKernelGGL(k_fold_angles, dim3((unsigned) ((nt + 255) / 256)), dim3(256), 0, h->stream, h->dPartials,
+                         h->maxOC, nOC, h->nMaps, orient0, convPerOrient, pang);
+    }
     hipLaunchKernelGGL(k_fold_wave, dim3((h->nMaps + 3) / 4), dim3(256), 0, h->stream, h->dPartials, h->maxOC, nOC,
                        h->nMaps, bb.params, h->dSumRef, h->dDisp, h->nd, h->pd, orient0, conv0, convPerOrient, pmap);
+  }
   HIP_CHECK(h, hipGetLastError());
   if (h->evPending.size() > 512)
     drain_events(h);

@@ -58,7 +58,37 @@ __global__ void k_fold(const Partial *__restrict__ partials, int ldPart, int nOC
 }
 
 // ------------------------------------------------------------------------------------------------
-// wave-parallel fold (no WRITE_PROB_ANGLES): one wave per particle; lane l folds a contiguous chunk of
+// WRITE_PROB_ANGLES table: one thread per (particle, orientation of this launch) folds that orientation's CTF
+// partials into its angle entry, in CTF order -- the same arithmetic sequence per entry as k_fold
+// (bioem_algorithm.h:130-141), but nMaps * nOrient threads instead of nMaps.  The particle entries are then
+// folded by k_fold_wave.
+// ------------------------------------------------------------------------------------------------
+__global__ void k_fold_angles(const Partial *__restrict__ partials, int ldPart, int nOC, int nMaps, int orient0,
+                              int convPerOrient, bioem_hip_prob_angle *__restrict__ pang)
+{
+  const int nOrient = (nOC + convPerOrient - 1) / convPerOrient;
+  const long long t = (long long) blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (long long) nOrient * nMaps)
+    return;
+  const int j = (int) (t / nMaps), p = (int) (t - (long long) j * nMaps); // particle index fastest: coalesced table
+  const Partial *P = partials + (size_t) p * ldPart;
+  bioem_hip_prob_angle pa = pang[(size_t) (orient0 + j) * nMaps + p];
+  for (int oc = j * convPerOrient; oc < min(nOC, (j + 1) * convPerOrient); oc++)
+  {
+    const Partial r = P[oc];
+    const double lp = (double) r.best;
+    if (pa.ConstAngle < lp)
+    {
+      pa.forAngles *= exp(-lp + pa.ConstAngle);
+      pa.ConstAngle = lp;
+    }
+    pa.forAngles += r.sumExp * exp(lp - pa.ConstAngle);
+  }
+  pang[(size_t) (orient0 + j) * nMaps + p] = pa;
+}
+
+// ------------------------------------------------------------------------------------------------
+// wave-parallel fold of the particle entries: one wave per particle; lane l folds a contiguous chunk of
 // (orientation, CTF) partials in order, the 64 chunk results are merged by a shuffle reduction that keeps
 // the FIRST maximum (lowest index), then combined with the running state exactly like the sequential fold.
 // The log-sum-exp merge is associative, so the result equals k_fold's up to double rounding (1e-16).
