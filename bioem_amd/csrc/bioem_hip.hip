@@ -168,7 +168,7 @@ namespace
 // host helpers
 // ------------------------------------------------------------------------------------------------
 size_t compare_lds_bytes(int N, int H, int NW, int waves)
-{ // generic kernel: tables + per-wave T [NW][Hs]
+{ // generic kernel: tables + per-wave T [nd rows][Hs]
   const int Hs = (H + 1) & ~1;
   return (size_t) ((N + 2) & ~1) * 8 + 256 + (size_t) waves * NW * Hs * 8;
 }
@@ -318,7 +318,7 @@ int launch_compare_fold(bioem_hip_ctx *h, const BatchBuf &bb, int nOC, int orien
   }
   else
   {
-    const size_t lds = compare_lds_bytes(h->N, h->H, 2 * h->pd.maxDisplaceCenter + 1, 4);
+    const size_t lds = compare_lds_bytes(h->N, h->H, h->nd, 4);
     hipLaunchKernelGGL(k_compare_generic, grid, dim3(256), lds, h->stream, a);
   }
   HIP_CHECK(h, hipGetLastError());
@@ -512,7 +512,7 @@ int bioem_hip_create(bioem_hip_handle *out, int device, const bioem_hip_param_de
   }
   // LDS budget check
   {
-    const size_t lds = h->fast ? fast_lds_bytes(N, 2 * h->winD + 1, 4) : compare_lds_bytes(N, h->H, 2 * maxD + 1, 4);
+    const size_t lds = h->fast ? fast_lds_bytes(N, 2 * h->winD + 1, 4) : compare_lds_bytes(N, h->H, h->nd, 4);
     if (lds > 160 * 1024)
     {
       h->err = "configuration exceeds the 160 KiB LDS budget of the comparison kernel";
@@ -523,7 +523,7 @@ int bioem_hip_create(bioem_hip_handle *out, int device, const bioem_hip_param_de
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
     else
     {
-      const size_t ldsg = compare_lds_bytes(N, h->H, 2 * maxD + 1, 4);
+      const size_t ldsg = compare_lds_bytes(N, h->H, h->nd, 4);
       HIP_CHECK(h, hipFuncSetAttribute(reinterpret_cast<const void *>(k_compare_generic),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int) ldsg));
     }

@@ -7,23 +7,26 @@ namespace
 {
 
 // ------------------------------------------------------------------------------------------------
-// generic comparison kernel: any N, any maxD.  Reference layout.  One wave per comparison;
-// T[dx][ky] = sum_kx X[kx][ky] w^(kx dx) by direct summation.
+// generic comparison kernel: any N, any window (odd N; more than 31 offsets per axis).  Reference layout.
+// One wave per comparison.  Column transform T[j][ky] = sum_kx X[kx][ky] w^(kx dx_j) by direct summation for the
+// nd displacement rows only: lane = frequency column, rows in chunks of 16 register accumulators, so X is formed
+// once per (kx, chunk) and each twiddle (uniform over the wave: one LDS broadcast read) feeds 64 columns.
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_compare_generic(const CompareArgs a)
 {
   extern __shared__ __align__(16) unsigned char smem[];
+  constexpr int CH = 16; // rows per register chunk
   const int N = a.N, H = a.H;
   const int Hs = (H + 1) & ~1;
-  const int NW = 2 * a.maxD + 1;
+  const int nd = a.nd;
   float2 *twl = reinterpret_cast<float2 *>(smem);
   int *displ = reinterpret_cast<int *>(smem + (size_t) ((N + 2) & ~1) * 8);
   float2 *Tall = reinterpret_cast<float2 *>(smem + (size_t) ((N + 2) & ~1) * 8 + 256);
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  float2 *Tl = Tall + (size_t) wave * NW * Hs;
+  const int wave = __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6)), lane = threadIdx.x & 63;
+  float2 *Tl = Tall + (size_t) wave * nd * Hs;
   for (int t = threadIdx.x; t <= N; t += blockDim.x)
     twl[t] = a.tw[t];
-  for (int t = threadIdx.x; t < a.nd; t += blockDim.x)
+  for (int t = threadIdx.x; t < nd; t += blockDim.x)
     displ[t] = a.disp[t];
   __syncthreads();
 
@@ -36,36 +39,55 @@ __global__ __launch_bounds__(256) void k_compare_generic(const CompareArgs a)
   const float2 *F = a.ref + (size_t) p * M;
   const float2 *C = a.conv + (size_t) oc * M;
 
-  for (int e = lane; e < NW * Hs; e += 64)
+  for (int ky0 = 0; ky0 < H; ky0 += 64)
   {
-    const int dxi = e / Hs, ky = e - dxi * Hs;
-    float tr = 0.f, ti = 0.f;
-    if (ky < H)
+    const int ky = ky0 + lane;
+    const int kyc = ky < H ? ky : H - 1;
+    float wgt = 2.f;
+    if (ky == 0 || (((N & 1) == 0) && ky == N / 2))
+      wgt = 1.f;
+    if (ky >= H)
+      wgt = 0.f;
+    for (int j0 = 0; j0 < nd; j0 += CH)
     {
-      const int dx = dxi - a.maxD;
-      const int step = dx < 0 ? dx + N : dx;
-      int idx = 0;
+      float tr[CH], ti[CH];
+      int step[CH], idx[CH]; // wave-uniform (SGPRs): twiddle index of row j at the current kx
+#pragma unroll
+      for (int j = 0; j < CH; j++)
+      {
+        tr[j] = 0.f;
+        ti[j] = 0.f;
+        const int dx = a.disp[min(j0 + j, nd - 1)]; // uniform scalar load
+        step[j] = dx < 0 ? dx + N : dx;
+        idx[j] = 0;
+      }
       for (int kx = 0; kx < N; kx++)
       {
-        const float2 c = C[(size_t) kx * H + ky], f = F[(size_t) kx * H + ky];
+        const float2 c = C[(size_t) kx * H + kyc], f = F[(size_t) kx * H + kyc];
+        // X = conv * conj(ref)   (bioem.cpp:1452-1455)
         const float xr = fmaf(c.x, f.x, c.y * f.y);
         const float xi = fmaf(c.y, f.x, -(c.x * f.y));
-        const float2 w = twl[idx];
-        tr = fmaf(xr, w.x, tr);
-        tr = fmaf(-xi, w.y, tr);
-        ti = fmaf(xr, w.y, ti);
-        ti = fmaf(xi, w.x, ti);
-        idx += step;
-        if (idx >= N)
-          idx -= N;
+#pragma unroll
+        for (int j = 0; j < CH; j++)
+        {
+          const float2 w = twl[idx[j]];
+          tr[j] = fmaf(xr, w.x, tr[j]);
+          tr[j] = fmaf(-xi, w.y, tr[j]);
+          ti[j] = fmaf(xr, w.y, ti[j]);
+          ti[j] = fmaf(xi, w.x, ti[j]);
+          idx[j] += step[j];
+          if (idx[j] >= N)
+            idx[j] -= N;
+        }
       }
-      float wgt = 2.f;
-      if (ky == 0 || (((N & 1) == 0) && ky == N / 2))
-        wgt = 1.f;
-      tr *= wgt;
-      ti *= wgt;
+      if (ky < Hs)
+      {
+#pragma unroll
+        for (int j = 0; j < CH; j++)
+          if (j0 + j < nd)
+            Tl[(size_t) (j0 + j) * Hs + ky] = make_float2(tr[j] * wgt, ti[j] * wgt);
+      }
     }
-    Tl[dxi * Hs + ky] = make_float2(tr, ti);
   }
   __syncthreads();
 
@@ -76,13 +98,12 @@ __global__ __launch_bounds__(256) void k_compare_generic(const CompareArgs a)
   const float nn = (float) (N * N);
   Lse L;
   lse_init(L);
-  const int nd = a.nd;
   for (int e = lane; e < nd * nd; e += 64)
   {
     const int ix = e / nd, iy = e - ix * nd;
     const int dy = displ[iy];
     const int step = dy < 0 ? dy + N : dy;
-    const float2 *row = Tl + (size_t) (displ[ix] + a.maxD) * Hs;
+    const float2 *row = Tl + (size_t) ix * Hs;
     float acc = 0.f;
     int idx = 0;
     for (int ky = 0; ky < H; ky++)
