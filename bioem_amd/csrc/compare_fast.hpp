@@ -156,6 +156,9 @@ __device__ __forceinline__ void window_accumulate(const float2 *Tl, const float2
       fft_inverse_mixed<R>(xr, xi);                                                                                \
   } while (0)
 #endif
+#ifndef BIOEM_MASK_IDLE_COLUMNS
+#define BIOEM_MASK_IDLE_COLUMNS 1
+#endif
 #ifndef BIOEM_BLOCK_BARRIER
 #define BIOEM_BLOCK_BARRIER 1
 #endif
@@ -313,6 +316,11 @@ __global__ __launch_bounds__(256, (WD <= 10 ? BIOEM_FAST_WAVES_PER_SIMD : 2)) vo
       Tr[d] = 0.f;
       Ti[d] = 0.f;
     }
+#if BIOEM_MASK_IDLE_COLUMNS
+    // lanes beyond the last column of the last block sit out the whole transform (EXEC masked once): their
+    // loads would only burn vector-memory cycles, and their T columns stay zero
+    if (ky < H)
+#endif
     for (int k1 = 0; k1 < N1; k1++)
     {
       float xr[R], xi[R];
