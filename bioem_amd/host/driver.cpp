@@ -192,13 +192,21 @@ int Driver::configure(int ac, char **av)
   nGpus = ndev;
   if (getenv("BIOEM_GPUS"))
     nGpus = std::max(1, std::min(ndev, atoi(getenv("BIOEM_GPUS"))));
+  // BIOEM_SHARDS=n: n orientation shards dealt round-robin over the selected GPUs (default: one per GPU); more
+  // shards than GPUs is only useful to rehearse the multi-GPU control flow and merge on a smaller machine
+  int nDevUsed = nGpus;
+  if (getenv("BIOEM_SHARDS"))
+    nGpus = std::max(1, atoi(getenv("BIOEM_SHARDS")));
   if (nGpus > param.nTotGridAngles)
     nGpus = param.nTotGridAngles;
+  nDevUsed = std::min(nDevUsed, nGpus);
   int firstDev = 0;
   if (getenv("GPUDEVICE") && atoi(getenv("GPUDEVICE")) >= 0) // bioem_cuda.cu:719-732
   {
     firstDev = atoi(getenv("GPUDEVICE"));
-    nGpus = 1;
+    if (!getenv("BIOEM_SHARDS"))
+      nGpus = 1;
+    nDevUsed = 1;
     if (firstDev >= ndev)
       fatal("GPUDEVICE %d out of range (%d devices)", firstDev, ndev);
   }
@@ -207,7 +215,8 @@ int Driver::configure(int ac, char **av)
   for (int g = 0; g < nGpus; g++)
   {
     bioem_hip_handle h = nullptr;
-    const int rc = bioem_hip_create(&h, firstDev + g, &param.pd, nMaps, param.nTotGridAngles, param.nTotCTFs, algo);
+    const int rc = bioem_hip_create(&h, firstDev + g % nDevUsed, &param.pd, nMaps, param.nTotGridAngles,
+                                    param.nTotCTFs, algo);
     handles[g] = h;
     check(h, rc, "bioem_hip_create");
     check(h, bioem_hip_upload_particle_maps(h, particles.maps.data()), "upload particles");

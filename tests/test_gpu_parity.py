@@ -250,8 +250,14 @@ CLI_CASES = ["g10_n64", "g9_n35_odd", "g4_n32_angles", "g5_n32_psf", "g11_n32_eu
              "g20_n256"]
 
 
-@pytest.mark.parametrize("name", CLI_CASES)
-def test_cli_end_to_end_against_reference_outputs(name, tmp_path):
+# (case, orientation shards): BIOEM_SHARDS > 1 runs the CLI's multi-GPU control flow (one engine context and host
+# thread per shard, private probability blocks, host log-sum-exp merge) with all shards on the one GPU of the box
+CLI_RUNS = [(c, 1) for c in CLI_CASES] + [("g10_n64", 3), ("g4_n32_angles", 2), ("g11_n32_eulerlist", 5),
+                                          ("g2_n128", 4)]
+
+
+@pytest.mark.parametrize("name,shards", CLI_RUNS)
+def test_cli_end_to_end_against_reference_outputs(name, shards, tmp_path):
     """The drop-in CLI (--Modelfile/--Particlesfile/--Inputfile[/--ReadOrientation][/--ReadMRC]) on the golden
     inputs, with the same files, options and environment the reference was run with: Output_Probabilities /
     ANG_PROB parsed and compared with the reference's own files; the header block must be byte-identical."""
@@ -273,7 +279,7 @@ def test_cli_end_to_end_against_reference_outputs(name, tmp_path):
             f.write("%d\n" % len(case["orient_lines"]) + "\n".join(case["orient_lines"]) + "\n")
         cmd += ["--ReadOrientation", "orient.txt"]
     for algo in case["algos"]:
-        env = dict(os.environ, BIOEM_ALGO=str(algo), BIOEM_GPUS="1")
+        env = dict(os.environ, BIOEM_ALGO=str(algo), BIOEM_GPUS="1", BIOEM_SHARDS=str(shards))
         env.update(case["env"])
         r = subprocess.run(cmd, cwd=str(d), env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True,
                            timeout=300)
