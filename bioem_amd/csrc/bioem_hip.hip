@@ -173,9 +173,9 @@ size_t compare_lds_bytes(int N, int H, int NW, int waves)
   return (size_t) ((N + 2) & ~1) * 8 + 256 + (size_t) waves * NW * Hs * 8;
 }
 
-size_t fast_lds_bytes(int N, int NW, int waves)
-{ // fast kernel: twiddles + displacement list + log table + per-wave T block [NW][66]
-  return (size_t) ((N + 2) & ~1) * 8 + 256 + 1024 + (size_t) waves * NW * 66 * 8;
+size_t fast_lds_bytes(int N, int NW, int waves, bool half)
+{ // fast kernel: twiddles + displacement list + log table + per-wave T block [NW][66] ([NW][34] with half exchange)
+  return (size_t) ((N + 2) & ~1) * 8 + 256 + 1024 + (size_t) waves * NW * (half ? 34 : 66) * 8;
 }
 
 hipEvent_t get_event(bioem_hip_ctx *h)
@@ -303,7 +303,7 @@ int launch_compare_fold(bioem_hip_ctx *h, const BatchBuf &bb, int nOC, int orien
   if (h->fast)
   {
     const int NW = 2 * h->winD + 1;
-    const size_t lds = fast_lds_bytes(h->N, NW, 4);
+    const size_t lds = fast_lds_bytes(h->N, NW, 4, fast_half_t(h->winD, 2 * h->fast));
     if (h->nyq)
     {
       const dim3 gridq((unsigned) (((size_t) (h->nMaps + 15) / 16) * ((nOC + 15) / 16)));
@@ -483,10 +483,19 @@ int bioem_hip_create(bioem_hip_handle *out, int device, const bioem_hip_param_de
     }
     h->gs = (gg >= 1 && gg <= 4) ? gg : 1;
   }
+  // window template: 2*winD+1 rows, nd <= rows (ALGO 1 with maxD % grid != 0 visits up to 2*(maxD/grid)+2 offsets)
+  {
+    const int mD = maxD / h->gs;
+    h->winD = (mD <= 5 && h->nd <= 11) ? 5 : (mD <= 10 && h->nd <= 21) ? 10 : 15;
+  }
   h->fast = 0;
   if (N % 2 == 0 && N >= 8 && maxD / h->gs <= 15 && h->nd <= 31)
   {
     int R = (N % 32 == 0) ? 32 : (N % 16 == 0) ? 16 : (N % 8 == 0) ? 8 : (N % 4 == 0) ? 4 : 2;
+    // 31-row window: a 16-point register FFT keeps the kernel at 3 waves per SIMD (see fast_half_t); sizes that
+    // take the Nyquist split (N/2 a multiple of 64) keep R = 32
+    if (h->winD == 15 && R == 32 && fast_half_t(15, 16) && (N / 2) % 64 != 0 && !getenv("BIOEM_WIDE_R32"))
+      R = 16;
     if (R < 8 && h->gs == 1 && !getenv("BIOEM_POW2_FFT"))
     { // power-of-two part 2 or 4: the largest 2/3/5-smooth even divisor <= 30 (mixed-radix register FFT) wins
       // (measured: 250^2 20 -> 40 M/s, 180^2 47 -> 53, 100^2 129 -> 143; with a part of 8 it does not: 200^2, 120^2)
@@ -505,14 +514,9 @@ int bioem_hip_create(bioem_hip_handle *out, int device, const bioem_hip_param_de
 #define BIOEM_NYQUIST_SPLIT 1
 #endif
   h->nyq = BIOEM_NYQUIST_SPLIT && h->fast && (N / 2) % 64 == 0 && N <= 1024; // k_nyquist_rows: twiddles of N <= 1024 in LDS
-  // window template: 2*winD+1 rows, nd <= rows (ALGO 1 with maxD % grid != 0 visits up to 2*(maxD/grid)+2 offsets)
-  {
-    const int mD = maxD / h->gs;
-    h->winD = (mD <= 5 && h->nd <= 11) ? 5 : (mD <= 10 && h->nd <= 21) ? 10 : 15;
-  }
   // LDS budget check
   {
-    const size_t lds = h->fast ? fast_lds_bytes(N, 2 * h->winD + 1, 4) : compare_lds_bytes(N, h->H, h->nd, 4);
+    const size_t lds = h->fast ? fast_lds_bytes(N, 2 * h->winD + 1, 4, fast_half_t(h->winD, 2 * h->fast)) : compare_lds_bytes(N, h->H, h->nd, 4);
     if (lds > 160 * 1024)
     {
       h->err = "configuration exceeds the 160 KiB LDS budget of the comparison kernel";

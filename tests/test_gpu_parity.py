@@ -413,6 +413,9 @@ def test_full_size_slice_against_oracle(full_workload):
                                               # 42 -> 6, 50 -> 10, 84 -> 12, 36 -> 18, 100 -> 20, 90/180/150 -> 30
                                               (56, 10, 1, 1), (44, 10, 1, 1), (34, 8, 1, 1), (42, 10, 1, 1),
                                               (84, 10, 1, 1), (120, 10, 1, 1), (150, 10, 1, 1), (300, 10, 1, 1),
+                                              # 31-row window: R = 16 + half-width T exchange (3 waves per SIMD); with
+                                              # the Nyquist split (128) it stays at R = 32
+                                              (224, 13, 1, 1), (128, 15, 1, 1), (160, 12, 1, 1), (200, 15, 1, 1),
                                               # small windows: the 11-row template (rows <= +-5)
                                               (224, 5, 1, 1), (128, 10, 2, 1), (64, 0, 1, 1), (96, 20, 4, 1),
                                               (80, 4, 2, 1), (224, 10, 2, 1)])
