@@ -110,6 +110,7 @@ struct bioem_hip_ctx
   int *dDisp = nullptr;
   double2 *dLtab = nullptr;
   float2 *dTwk = nullptr;
+  float2 *dTwNyq = nullptr; // [N/2 row pairs][2*winD+1][2] twiddles of the Nyquist pre-kernel (nyq only)
   float *dTnyq = nullptr; // [nMaps][maxOC][2*winD+1] Nyquist-column rows of the current launch (nyq only)
 
   double *dProjReal = nullptr; // [chunkB][N*N]
@@ -278,6 +279,7 @@ int launch_compare_fold(bioem_hip_ctx *h, const BatchBuf &bb, int nOC, int orien
   a.ltab = h->dLtab;
   a.twk = h->dTwk;
   a.tnyq = h->dTnyq;
+  a.twnyq = h->dTwNyq;
   a.partials = h->dPartials;
   a.ldPart = h->maxOC;
   a.N = h->N;
@@ -513,7 +515,7 @@ int bioem_hip_create(bioem_hip_handle *out, int device, const bioem_hip_param_de
 #ifndef BIOEM_NYQUIST_SPLIT
 #define BIOEM_NYQUIST_SPLIT 1
 #endif
-  h->nyq = BIOEM_NYQUIST_SPLIT && h->fast && (N / 2) % 64 == 0 && N <= 1024; // k_nyquist_rows: twiddles of N <= 1024 in LDS
+  h->nyq = BIOEM_NYQUIST_SPLIT && h->fast && (N / 2) % 64 == 0;
   // LDS budget check
   {
     const size_t lds = h->fast ? fast_lds_bytes(N, 2 * h->winD + 1, 4, fast_half_t(h->winD, 2 * h->fast)) : compare_lds_bytes(N, h->H, h->nd, 4);
@@ -629,6 +631,22 @@ int bioem_hip_create(bioem_hip_handle *out, int device, const bioem_hip_param_de
       }
     HIP_CHECK(h, hipMalloc(&h->dTwk, sizeof(float2) * twk.size()));
     HIP_CHECK(h, hipMemcpy(h->dTwk, twk.data(), sizeof(float2) * twk.size(), hipMemcpyHostToDevice));
+    if (h->nyq)
+    { // Nyquist pre-kernel: per (k1, k2 pair) the 2*winD+1 twiddle pairs w^(kx0 m gs), w^(kx1 m gs), contiguous
+      const int R2 = h->fast;
+      std::vector<float2> twn((size_t) (N / 2) * NW * 2);
+      for (int k1 = 0; k1 < h->N1; k1++)
+        for (int k2p = 0; k2p < R2; k2p++)
+          for (int m = -h->winD; m <= h->winD; m++)
+            for (int e = 0; e < 2; e++)
+            {
+              const long long kx = (long long) h->N1 * (2 * k2p + e) + k1;
+              const int idx = (int) (((kx * m * h->gs) % N + N) % N);
+              twn[(((size_t) (k1 * R2 + k2p) * NW) + (m + h->winD)) * 2 + e] = tw[idx];
+            }
+      HIP_CHECK(h, hipMalloc(&h->dTwNyq, sizeof(float2) * twn.size()));
+      HIP_CHECK(h, hipMemcpy(h->dTwNyq, twn.data(), sizeof(float2) * twn.size(), hipMemcpyHostToDevice));
+    }
   }
   HIP_CHECK(h, hipEventCreateWithFlags(&h->slotEvent[0], hipEventDisableTiming));
   HIP_CHECK(h, hipEventCreateWithFlags(&h->slotEvent[1], hipEventDisableTiming));
@@ -649,7 +667,7 @@ int bioem_hip_destroy(bioem_hip_handle h)
                   h->dTw,      h->dTwD,     h->dDisp,     h->dLtab,    h->dTwk,     h->dProjReal, h->dTempDen,  h->dRowSpec, h->dSpecRef,
                   h->dScratch, h->dConv,    h->dParams,   h->dPartials, h->dProb,     h->dStage,
                   h->dProjReal2, h->dTempDen2, h->dRowSpec2, h->dSpecRef2, h->dScratch2, h->dConv2, h->dParams2,
-                  h->dTnyq};
+                  h->dTnyq, h->dTwNyq};
   for (void *p : ptrs)
     if (p)
       hipFree(p);

@@ -474,18 +474,14 @@ __global__ __launch_bounds__(256, fast_waves_per_simd(WD, R)) void k_compare_fas
 // Nyquist-column rows for the fast kernel's NYQ mode: thread = one (particle, orientation*CTF) pair, tile of
 // 16 x 16 pairs per block (each operand line is shared by 16 threads).
 //   tnyq[p][oc][m + WD] = Re sum_kx conv[oc][kx][N/2] * conj(ref[p][kx][N/2]) * w_N^(kx m gs),  m = -WD..WD
-// The twiddle index is uniform over the block (LDS broadcast reads).
+// The twiddles are uniform over the block and tabulated per row pair (twnyq): wide scalar loads.
 // ------------------------------------------------------------------------------------------------
 template <int WD>
 __global__ __launch_bounds__(256) void k_nyquist_rows(const CompareArgs a)
 {
   constexpr int NW = 2 * WD + 1;
-  __shared__ float2 twl[1024];
   const int N = a.N, H = a.H, N1 = a.N1;
   const int R2 = N / (2 * N1);
-  for (int t = threadIdx.x; t < N; t += blockDim.x)
-    twl[t] = a.tw[t];
-  __syncthreads();
   const int tilesOC = (a.nOC + 15) / 16;
   const int tp = blockIdx.x / tilesOC, to = blockIdx.x - tp * tilesOC;
   const int p = tp * 16 + (threadIdx.x >> 4), oc = to * 16 + (threadIdx.x & 15);
@@ -497,38 +493,29 @@ __global__ __launch_bounds__(256) void k_nyquist_rows(const CompareArgs a)
 #pragma unroll
   for (int d = 0; d < NW; d++)
     acc[d] = 0.f;
-  for (int k1 = 0; k1 < N1; k1++)
-    for (int k2p = 0; k2p < R2; k2p++)
-    {
-      // the two k2 of a pair are adjacent in the comparison layout: one 16-byte load per operand
-      const size_t li = ((size_t) (k1 * R2 + k2p) * H + N / 2) * 2;
-      const float4 c = *reinterpret_cast<const float4 *>(C + li);
-      const float4 f = *reinterpret_cast<const float4 *>(F + li);
-      // X = conv * conj(ref)   (bioem.cpp:1452-1455)
-      const float x0r = fmaf(c.x, f.x, c.y * f.y), x0i = fmaf(c.y, f.x, -(c.x * f.y));
-      const float x1r = fmaf(c.z, f.z, c.w * f.w), x1i = fmaf(c.w, f.z, -(c.z * f.w));
-      const int kx0 = N1 * (2 * k2p) + k1, kx1 = kx0 + N1;
-      // w^(kx * dx) for dx = -WD*gs, then dx -> dx + gs
-      const int s0 = (int) (((long long) kx0 * a.gs) % N), s1 = (int) (((long long) kx1 * a.gs) % N);
-      int i0 = (int) ((N - ((long long) s0 * WD) % N) % N), i1 = (int) ((N - ((long long) s1 * WD) % N) % N);
+  for (int rp = 0; rp < N1 * R2; rp++) // row pair = (k1, k2 pair): kx0 = N1*(2 k2p) + k1, kx1 = kx0 + N1
+  {
+    // the two k2 of a pair are adjacent in the comparison layout: one 16-byte load per operand
+    const size_t li = ((size_t) rp * H + N / 2) * 2;
+    const float4 c = *reinterpret_cast<const float4 *>(C + li);
+    const float4 f = *reinterpret_cast<const float4 *>(F + li);
+    // X = conv * conj(ref)   (bioem.cpp:1452-1455)
+    const float x0r = fmaf(c.x, f.x, c.y * f.y), x0i = fmaf(c.y, f.x, -(c.x * f.y));
+    const float x1r = fmaf(c.z, f.z, c.w * f.w), x1i = fmaf(c.w, f.z, -(c.z * f.w));
+    // twiddles of this row pair: block-uniform, contiguous -> a few wide scalar loads
+    const float4 *tw = reinterpret_cast<const float4 *>(a.twnyq + (size_t) rp * NW * 2);
 #pragma unroll
-      for (int d = 0; d < NW; d++)
-      {
-        const float2 w0 = twl[i0], w1 = twl[i1];
-        float v = acc[d];
-        v = fmaf(x0r, w0.x, v);
-        v = fmaf(-x0i, w0.y, v);
-        v = fmaf(x1r, w1.x, v);
-        v = fmaf(-x1i, w1.y, v);
-        acc[d] = v;
-        i0 += s0;
-        if (i0 >= N)
-          i0 -= N;
-        i1 += s1;
-        if (i1 >= N)
-          i1 -= N;
-      }
+    for (int d = 0; d < NW; d++)
+    {
+      const float4 w = tw[d]; // (w0.re, w0.im, w1.re, w1.im)
+      float v = acc[d];
+      v = fmaf(x0r, w.x, v);
+      v = fmaf(-x0i, w.y, v);
+      v = fmaf(x1r, w.z, v);
+      v = fmaf(-x1i, w.w, v);
+      acc[d] = v;
     }
+  }
   if (valid)
   {
     float *o = a.tnyq + ((size_t) p * a.ldPart + oc) * NW;
