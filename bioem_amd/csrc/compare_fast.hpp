@@ -135,16 +135,8 @@ __device__ __forceinline__ void window_accumulate(const float2 *Tl, const float2
 // FFTs -> T block in LDS -> window accumulation, so the LDS footprint per wave is (2*WD+1)*64*8 bytes
 // (10.5 KiB for +-10 px => 3 blocks per CU, matching the VGPR-limited 3 waves per SIMD).
 // ------------------------------------------------------------------------------------------------
-// FFT flavour: decimation in time with 6-op butterflies (default) or the decimation-in-frequency original
-// (R = 32 only)
-#ifndef BIOEM_FFT_DIF
-#define BIOEM_FFT_DIF 0
-#endif
-#if BIOEM_FFT_DIF
-#define FFT_IN(k) (k)
-#define FFT_OUT(n) bitrev5(n)
-#define FFT_RUN(xr, xi) fft32_inverse(xr, xi)
-#else
+// register FFT: radix-2 decimation in time with 6-op butterflies for power-of-two lengths, mixed radix otherwise;
+// inputs go to the (bit- or digit-) reversed position, outputs come out in natural order
 #define FFT_IN(k) (is_pow2(R) ? bitrevR<R>(k) : DIGITREV<R>.pos[k])
 #define FFT_OUT(n) (n)
 #define FFT_RUN(xr, xi)                                                                                            \
@@ -155,7 +147,6 @@ __device__ __forceinline__ void window_accumulate(const float2 *Tl, const float2
     else                                                                                                           \
       fft_inverse_mixed<R>(xr, xi);                                                                                \
   } while (0)
-#endif
 #ifndef BIOEM_MASK_IDLE_COLUMNS
 #define BIOEM_MASK_IDLE_COLUMNS 1
 #endif

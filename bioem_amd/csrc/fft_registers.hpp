@@ -7,7 +7,7 @@ namespace
 {
 
 // ------------------------------------------------------------------------------------------------
-// 32-point inverse FFT in registers: radix-2 decimation in frequency, sign +, output bit-reversed.
+// exp(+2 pi i t / 32), t = 0..15: twiddles of the radix-2 register FFTs
 // ------------------------------------------------------------------------------------------------
 __device__ constexpr float COS32[16] = {1.0f,
                                         0.98078528040323044913f,
@@ -41,50 +41,6 @@ __device__ constexpr float SIN32[16] = {0.0f,
                                         0.55557023301960222474f,
                                         0.38268343236508977173f,
                                         0.19509032201612826785f};
-
-__host__ __device__ constexpr int bitrev5(int n)
-{
-  return ((n & 1) << 4) | ((n & 2) << 2) | (n & 4) | ((n & 8) >> 2) | ((n & 16) >> 4);
-}
-
-__device__ __forceinline__ void fft32_inverse(float (&xr)[32], float (&xi)[32])
-{
-#pragma unroll
-  for (int s = 0; s < 5; s++)
-  {
-    const int m = 16 >> s;
-#pragma unroll
-    for (int b = 0; b < 32; b += 2 * m)
-    {
-#pragma unroll
-      for (int j = 0; j < m; j++)
-      {
-        const int i0 = b + j, i1 = b + j + m;
-        const int t = j << s;
-        const float ar = xr[i0], ai = xi[i0], br = xr[i1], bi = xi[i1];
-        xr[i0] = ar + br;
-        xi[i0] = ai + bi;
-        const float dr = ar - br, di = ai - bi;
-        if (t == 0)
-        {
-          xr[i1] = dr;
-          xi[i1] = di;
-        }
-        else if (t == 8)
-        {
-          xr[i1] = -di;
-          xi[i1] = dr;
-        }
-        else
-        {
-          const float c = COS32[t], sn = SIN32[t];
-          xr[i1] = fmaf(dr, c, -(di * sn));
-          xi[i1] = fmaf(dr, sn, di * c);
-        }
-      }
-    }
-  }
-}
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
