@@ -66,7 +66,7 @@ def main():
     ap.add_argument("--grid", type=int, default=1, help="DISPLACE_CENTER grid spacing")
     ap.add_argument("--write-angles", action="store_true", help="WRITE_PROB_ANGLES: keep the per-orientation table")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-orientations", type=int, default=16)
+    ap.add_argument("--cpu-orientations", type=int, default=64, help="orientations of the CPU-baseline sample (~12 s)")
     args = ap.parse_args()
 
     import torch
