@@ -88,6 +88,12 @@ struct bioem_hip_ctx
                                   // 1 000 particles 6.73 -> 6.56 ms, 10 000 particles (2 GB, beyond the Infinity
                                   // Cache) 78.5 -> 63.2 ms per launch
   int gs = 1;                     // pixels per window row of the fast kernel (gcd of the displacement offsets)
+  // wide windows (more than 31 offsets per axis): tilesPerAxis^2 launches of a tileT-row window (window_tiles.hpp)
+  int tileT = 0, tilesPerAxis = 1;
+  std::vector<int> tileCenter, tileValid; // per axis tile: centre (in window rows) and number of rows inside the window
+  int *dDispLocal = nullptr, *dTileCenter = nullptr, *dRankOfRow = nullptr;
+  float2 *dConvShift = nullptr;
+  Partial *dPartTiles = nullptr;
   bool nyq = false;               // Nyquist column handled outside the 64-column blocks (N/2 a multiple of 64)
   int nd = 0;                     // displacements per axis
   std::vector<int> disp;
@@ -161,6 +167,7 @@ struct bioem_hip_ctx
 #include "compare_fast.hpp"
 #include "compare_generic.hpp"
 #include "fold_kernels.hpp"
+#include "window_tiles.hpp"
 
 namespace
 {
@@ -292,6 +299,7 @@ int launch_compare_fold(bioem_hip_ctx *h, const BatchBuf &bb, int nOC, int orien
   a.algo = h->algo;
   a.pd = h->pd;
   a.gs = h->gs;
+  a.ndx = a.ndy = h->nd;
   a.pchunk = h->pchunk > 0 ? std::min(h->pchunk, h->nMaps) : h->nMaps;
   const int ocGroups = (nOC + 3) / 4;
   const dim3 grid((unsigned) ((size_t) ocGroups * h->nMaps));
@@ -306,17 +314,52 @@ int launch_compare_fold(bioem_hip_ctx *h, const BatchBuf &bb, int nOC, int orien
   {
     const int NW = 2 * h->winD + 1;
     const size_t lds = fast_lds_bytes(h->N, NW, 4, fast_half_t(h->winD, 2 * h->fast));
-    if (h->nyq)
-    {
-      const dim3 gridq((unsigned) (((size_t) (h->nMaps + 15) / 16) * ((nOC + 15) / 16)));
-      if (h->winD == 5)
-        hipLaunchKernelGGL(k_nyquist_rows<5>, gridq, dim3(256), 0, h->stream, a);
-      else if (h->winD == 10)
-        hipLaunchKernelGGL(k_nyquist_rows<10>, gridq, dim3(256), 0, h->stream, a);
-      else
-        hipLaunchKernelGGL(k_nyquist_rows<15>, gridq, dim3(256), 0, h->stream, a);
+    auto launch_window = [&](const CompareArgs &aw) {
+      if (h->nyq)
+      {
+        const dim3 gridq((unsigned) (((size_t) (h->nMaps + 15) / 16) * ((nOC + 15) / 16)));
+        if (h->winD == 5)
+          hipLaunchKernelGGL(k_nyquist_rows<5>, gridq, dim3(256), 0, h->stream, aw);
+        else if (h->winD == 10)
+          hipLaunchKernelGGL(k_nyquist_rows<10>, gridq, dim3(256), 0, h->stream, aw);
+        else
+          hipLaunchKernelGGL(k_nyquist_rows<15>, gridq, dim3(256), 0, h->stream, aw);
+      }
+      hipLaunchKernelGGL(fast_kernel(h->winD, 2 * h->fast, h->nyq, h->gs), grid, dim3(256), lds, h->stream, aw);
+    };
+    if (!h->tileT)
+      launch_window(a);
+    else
+    { // wide window: one launch per tile on the phase-shifted conv spectra, then merge (window_tiles.hpp)
+      const int nT = h->tilesPerAxis;
+      const size_t tileStride = (size_t) h->nMaps * h->maxOC;
+      const size_t total = (size_t) nOC * h->M;
+      CompareArgs at = a;
+      at.disp = h->dDispLocal;
+      at.nd = h->tileT;
+      at.maxD = h->winD * h->gs;
+      for (int tx = 0; tx < nT; tx++)
+        for (int ty = 0; ty < nT; ty++)
+        {
+          const int sx = h->gs * h->tileCenter[tx], sy = h->gs * h->tileCenter[ty];
+          if (sx == 0 && sy == 0)
+            at.conv = bb.conv;
+          else
+          {
+            hipLaunchKernelGGL(k_phase_shift, dim3(2048), dim3(256), 0, h->stream, bb.conv, h->dConvShift, total, h->N,
+                               h->H, h->fast, h->N1, sx, sy, h->dTw);
+            at.conv = h->dConvShift;
+          }
+          at.ndx = h->tileValid[tx];
+          at.ndy = h->tileValid[ty];
+          at.partials = h->dPartTiles + (size_t) (tx * nT + ty) * tileStride;
+          launch_window(at);
+        }
+      const long long nt = (long long) nOC * h->nMaps;
+      hipLaunchKernelGGL(k_merge_tiles, dim3((unsigned) ((nt + 255) / 256)), dim3(256), 0, h->stream, h->dPartTiles,
+                         nT * nT, tileStride, h->maxOC, nOC, h->nMaps, h->tileT, nT, h->dTileCenter,
+                         h->pd.maxDisplaceCenter / h->gs, h->nd, h->dRankOfRow, h->dPartials);
     }
-    hipLaunchKernelGGL(fast_kernel(h->winD, 2 * h->fast, h->nyq, h->gs), grid, dim3(256), lds, h->stream, a);
   }
   else
   {
@@ -486,12 +529,30 @@ int bioem_hip_create(bioem_hip_handle *out, int device, const bioem_hip_param_de
     h->gs = (gg >= 1 && gg <= 4) ? gg : 1;
   }
   // window template: 2*winD+1 rows, nd <= rows (ALGO 1 with maxD % grid != 0 visits up to 2*(maxD/grid)+2 offsets)
+  const int mD = maxD / h->gs;
+  h->winD = (mD <= 5 && h->nd <= 11) ? 5 : (mD <= 10 && h->nd <= 21) ? 10 : 15;
+  // wide windows: more rows than the 31-row template -> tiles of 21 or 31 rows (window_tiles.hpp); needs the plain
+  // symmetric set {gs*m, |m| <= mD}
+  h->tileT = 0;
+  h->tilesPerAxis = 1;
+  if (N % 2 == 0 && N >= 8 && (mD > 15 || h->nd > 31) && h->nd == 2 * mD + 1 && !getenv("BIOEM_NO_TILES"))
   {
-    const int mD = maxD / h->gs;
-    h->winD = (mD <= 5 && h->nd <= 11) ? 5 : (mD <= 10 && h->nd <= 21) ? 10 : 15;
+    const int W = h->nd;
+    const int t21 = (W + 20) / 21, t31 = (W + 30) / 31;
+    // launches^2 x the measured cost of one launch of the 21- / 31-row kernel (6.5 / 10.1 ms at 224^2)
+    h->tileT = (t21 * t21 * 6.5 <= t31 * t31 * 10.1) ? 21 : 31;
+    if (getenv("BIOEM_TILE_ROWS"))
+      h->tileT = atoi(getenv("BIOEM_TILE_ROWS")) == 31 ? 31 : 21;
+    h->tilesPerAxis = (W + h->tileT - 1) / h->tileT;
+    h->winD = (h->tileT - 1) / 2;
+    for (int k = 0; k < h->tilesPerAxis; k++)
+    {
+      h->tileCenter.push_back(-mD + k * h->tileT + h->winD);               // centre row of tile k
+      h->tileValid.push_back(std::min(h->tileT, W - k * h->tileT));        // rows of tile k inside the window
+    }
   }
   h->fast = 0;
-  if (N % 2 == 0 && N >= 8 && maxD / h->gs <= 15 && h->nd <= 31)
+  if (N % 2 == 0 && N >= 8 && ((maxD / h->gs <= 15 && h->nd <= 31) || h->tileT))
   {
     int R = (N % 32 == 0) ? 32 : (N % 16 == 0) ? 16 : (N % 8 == 0) ? 8 : (N % 4 == 0) ? 4 : 2;
     // 31-row window: a 16-point register FFT keeps the kernel at 3 waves per SIMD (see fast_half_t); sizes that
@@ -538,7 +599,11 @@ int bioem_hip_create(bioem_hip_handle *out, int device, const bioem_hip_param_de
   // batch sizing: conv buffer <= ~96 MiB, partial buffer <= ~128 MiB
   const size_t M = (size_t) h->M;
   size_t ocCap = (96u << 20) / (M * sizeof(float2));
-  const size_t partCap = (128u << 20) / ((size_t) nMaps * sizeof(Partial));
+  // (tiled wide windows keep one partial per tile and comparison besides the merged one)
+  const size_t partBuffers = 1 + (h->tileT ? (size_t) h->tilesPerAxis * h->tilesPerAxis : 0);
+  size_t partCap = (128u << 20) / ((size_t) nMaps * sizeof(Partial));
+  if (partBuffers > 1)
+    partCap = std::max<size_t>((size_t) nCTF, (1024u << 20) / ((size_t) nMaps * sizeof(Partial) * partBuffers));
   if (ocCap > partCap)
     ocCap = partCap;
   int OB = (int) (ocCap / (size_t) nCTF);
@@ -576,6 +641,23 @@ int bioem_hip_create(bioem_hip_handle *out, int device, const bioem_hip_param_de
   HIP_CHECK(h, hipMalloc(&h->dPartials, sizeof(Partial) * (size_t) nMaps * h->maxOC));
   if (h->nyq)
     HIP_CHECK(h, hipMalloc(&h->dTnyq, sizeof(float) * (size_t) nMaps * h->maxOC * (2 * h->winD + 1)));
+  if (h->tileT)
+  {
+    const int nT = h->tilesPerAxis;
+    HIP_CHECK(h, hipMalloc(&h->dPartTiles, sizeof(Partial) * (size_t) nT * nT * nMaps * h->maxOC));
+    HIP_CHECK(h, hipMalloc(&h->dConvShift, sizeof(float2) * (size_t) h->maxOC * M));
+    std::vector<int> local(h->tileT), rank(2 * mD + 1, 0);
+    for (int j = 0; j < h->tileT; j++)
+      local[j] = h->gs * (j - h->winD); // sorted local list: the kernel's rows and lanes in the same order
+    for (int v = 0; v < h->nd; v++)
+      rank[h->disp[v] / h->gs + mD] = v; // visiting rank of window row m in the reference's order
+    HIP_CHECK(h, hipMalloc(&h->dDispLocal, sizeof(int) * local.size()));
+    HIP_CHECK(h, hipMemcpy(h->dDispLocal, local.data(), sizeof(int) * local.size(), hipMemcpyHostToDevice));
+    HIP_CHECK(h, hipMalloc(&h->dRankOfRow, sizeof(int) * rank.size()));
+    HIP_CHECK(h, hipMemcpy(h->dRankOfRow, rank.data(), sizeof(int) * rank.size(), hipMemcpyHostToDevice));
+    HIP_CHECK(h, hipMalloc(&h->dTileCenter, sizeof(int) * nT));
+    HIP_CHECK(h, hipMemcpy(h->dTileCenter, h->tileCenter.data(), sizeof(int) * nT, hipMemcpyHostToDevice));
+  }
   h->probBytes = bioem_hip_prob_size(nMaps, nAngles, pd->writeAngles);
   HIP_CHECK(h, hipMalloc(&h->dProb, h->probBytes));
   {
@@ -667,7 +749,7 @@ int bioem_hip_destroy(bioem_hip_handle h)
                   h->dTw,      h->dTwD,     h->dDisp,     h->dLtab,    h->dTwk,     h->dProjReal, h->dTempDen,  h->dRowSpec, h->dSpecRef,
                   h->dScratch, h->dConv,    h->dParams,   h->dPartials, h->dProb,     h->dStage,
                   h->dProjReal2, h->dTempDen2, h->dRowSpec2, h->dSpecRef2, h->dScratch2, h->dConv2, h->dParams2,
-                  h->dTnyq, h->dTwNyq};
+                  h->dTnyq, h->dTwNyq, h->dPartTiles, h->dConvShift, h->dDispLocal, h->dRankOfRow, h->dTileCenter};
   for (void *p : ptrs)
     if (p)
       hipFree(p);

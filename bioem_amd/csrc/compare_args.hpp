@@ -23,6 +23,9 @@ struct CompareArgs
   int N, H, N1, nd, maxD, nOC, nMaps, algo;
   int pchunk; // particles per block-order chunk of the fast kernel
   int gs;     // pixels per window row of the fast kernel (template GS)
+  // window tiles (wide windows are covered by several launches over phase-shifted conv spectra): only the first
+  // ndx rows (sorted order) and the first ndy lanes of the displacement list count; nd for an untiled launch
+  int ndx, ndy;
   PD pd;
 };
 

@@ -436,7 +436,7 @@ __global__ __launch_bounds__(256, fast_waves_per_simd(WD, R)) void k_compare_fas
   for (int r = 0; r < NR; r++)
   {
     const int ixs = grp * nr + r; // position in the lane-group order; ix = visiting rank of that displacement
-    if (r < nr && wactive && ixs < nd)
+    if (r < nr && wactive && ixs < a.ndx && iy < a.ndy)
     {
       const int ix = is_static ? dinv[ixs] : ixs;
       const float cc = acc[r] / nn;

@@ -405,7 +405,7 @@ def test_full_size_slice_against_oracle(full_workload):
 @pytest.mark.parametrize("N,maxD,grid,fast", [(40, 10, 1, 1), (72, 7, 1, 1), (200, 10, 1, 1), (80, 12, 1, 1),
                                               (48, 15, 1, 1), (96, 10, 2, 1), (160, 10, 1, 1), (256, 10, 1, 1),
                                               (100, 10, 1, 1), (36, 5, 1, 1), (180, 10, 1, 1), (250, 10, 1, 1),
-                                              (90, 9, 3, 1), (10, 2, 1, 1), (75, 10, 1, 0), (64, 16, 1, 0),
+                                              (90, 9, 3, 1), (10, 2, 1, 1), (75, 10, 1, 0), (64, 16, 1, 1),
                                               # coarse grids: window rows step by the gcd of the offsets (1..4)
                                               (64, 30, 2, 1), (224, 20, 2, 1), (128, 40, 4, 1), (96, 45, 3, 1),
                                               (64, 9, 2, 1), (100, 25, 5, 0), (64, 31, 2, 0),
@@ -416,6 +416,10 @@ def test_full_size_slice_against_oracle(full_workload):
                                               # 31-row window: R = 16 + half-width T exchange (3 waves per SIMD); with
                                               # the Nyquist split (128) it stays at R = 32
                                               (224, 13, 1, 1), (128, 15, 1, 1), (160, 12, 1, 1), (200, 15, 1, 1),
+                                              # wide windows (the reference's tutorial suggests DISPLACE_CENTER 40 1):
+                                              # tiles of the 21- / 31-row window on phase-shifted conv spectra
+                                              (64, 20, 1, 1), (128, 40, 1, 1), (224, 20, 1, 1), (100, 40, 2, 1),
+                                              (64, 31, 1, 1), (96, 16, 1, 1), (256, 25, 1, 1), (75, 20, 1, 0),
                                               # small windows: the 11-row template (rows <= +-5)
                                               (224, 5, 1, 1), (128, 10, 2, 1), (64, 0, 1, 1), (96, 20, 4, 1),
                                               (80, 4, 2, 1), (224, 10, 2, 1)])
