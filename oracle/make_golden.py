@@ -214,6 +214,16 @@ def case_table():
                          kw=[("CTF_B_ENV", [2.0, 300.0, 2]), ("CTF_DEFOCUS", [2.0, 2.0, 1]),
                              ("CTF_AMPLITUDE", [0.1, 0.1, 1]), ("DISPLACE_CENTER", [10, 1])],
                          algos=[1, 2], snr=0.05, maxshift=8, seed=120)
+    # G21-G22: wide translation windows (the tutorial's production setting is DISPLACE_CENTER 40 1): more offsets per
+    # axis than the device kernel's 31-row window -> tiled launches
+    C["g21_n64_wide20"] = dict(N=64, px=2.2, nP=4, npts=100, extent=30.0, rad=(2.25, 3.4), orient=("list", 12),
+                               kw=[("CTF_B_ENV", [20.0, 200.0, 2]), ("CTF_DEFOCUS", [1.0, 3.0, 2]),
+                                   ("CTF_AMPLITUDE", [0.1, 0.1, 1]), ("DISPLACE_CENTER", [20, 1])],
+                               algos=[1, 2], snr=0.1, maxshift=15, seed=121)
+    C["g22_n128_wide40"] = dict(N=128, px=1.77, nP=3, npts=300, extent=45.0, rad=(2.25, 3.4), orient=("list", 8),
+                                kw=[("CTF_B_ENV", [2.0, 300.0, 2]), ("CTF_DEFOCUS", [2.0, 2.0, 1]),
+                                    ("CTF_AMPLITUDE", [0.1, 0.1, 1]), ("DISPLACE_CENTER", [40, 1])],
+                                algos=[1, 2], snr=0.05, maxshift=30, seed=122)
     only = os.environ.get("BIOEM_GOLDEN_ONLY")  # e.g. "g16,g17": restrict every stage to cases with these prefixes
     if only:
         C = {k: v for k, v in C.items() if any(k.startswith(o + "_") for o in only.split(","))}
