@@ -89,6 +89,7 @@ struct bioem_hip_ctx
                                   // Cache) 78.5 -> 63.2 ms per launch
   int gs = 1;                     // pixels per window row of the fast kernel (gcd of the displacement offsets)
   // wide windows (more than 31 offsets per axis): tilesPerAxis^2 launches of a tileT-row window (window_tiles.hpp)
+  int genericWaves = 4; // waves per block of the generic kernel
   int tileT = 0, tilesPerAxis = 1;
   std::vector<int> tileCenter, tileValid; // per axis tile: centre (in window rows) and number of rows inside the window
   int *dDispLocal = nullptr, *dTileCenter = nullptr, *dRankOfRow = nullptr;
@@ -178,7 +179,8 @@ namespace
 size_t compare_lds_bytes(int N, int H, int NW, int waves)
 { // generic kernel: tables + per-wave T [nd rows][Hs]
   const int Hs = (H + 1) & ~1;
-  return (size_t) ((N + 2) & ~1) * 8 + 256 + (size_t) waves * NW * Hs * 8;
+  const size_t dispBytes = ((size_t) NW * 4 + 255) & ~(size_t) 255;
+  return (size_t) ((N + 2) & ~1) * 8 + dispBytes + (size_t) waves * NW * Hs * 8;
 }
 
 size_t fast_lds_bytes(int N, int NW, int waves, bool half)
@@ -363,8 +365,10 @@ int launch_compare_fold(bioem_hip_ctx *h, const BatchBuf &bb, int nOC, int orien
   }
   else
   {
-    const size_t lds = compare_lds_bytes(h->N, h->H, h->nd, 4);
-    hipLaunchKernelGGL(k_compare_generic, grid, dim3(256), lds, h->stream, a);
+    const int gw = h->genericWaves;
+    const size_t lds = compare_lds_bytes(h->N, h->H, h->nd, gw);
+    const dim3 gridg((unsigned) ((size_t) ((nOC + gw - 1) / gw) * h->nMaps));
+    hipLaunchKernelGGL(k_compare_generic, gridg, dim3(64 * gw), lds, h->stream, a);
   }
   HIP_CHECK(h, hipGetLastError());
   HIP_CHECK(h, hipEventRecord(e1, h->stream));
@@ -579,7 +583,12 @@ int bioem_hip_create(bioem_hip_handle *out, int device, const bioem_hip_param_de
   h->nyq = BIOEM_NYQUIST_SPLIT && h->fast && (N / 2) % 64 == 0;
   // LDS budget check
   {
-    const size_t lds = h->fast ? fast_lds_bytes(N, 2 * h->winD + 1, 4, fast_half_t(h->winD, 2 * h->fast)) : compare_lds_bytes(N, h->H, h->nd, 4);
+    // generic kernel: as many waves per block (4, 2, 1) as its per-wave T block [nd][H] lets fit
+    h->genericWaves = 4;
+    while (!h->fast && h->genericWaves > 1 && compare_lds_bytes(N, h->H, h->nd, h->genericWaves) > 160 * 1024)
+      h->genericWaves >>= 1;
+    const size_t lds = h->fast ? fast_lds_bytes(N, 2 * h->winD + 1, 4, fast_half_t(h->winD, 2 * h->fast))
+                               : compare_lds_bytes(N, h->H, h->nd, h->genericWaves);
     if (lds > 160 * 1024)
     {
       h->err = "configuration exceeds the 160 KiB LDS budget of the comparison kernel";
@@ -590,7 +599,7 @@ int bioem_hip_create(bioem_hip_handle *out, int device, const bioem_hip_param_de
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
     else
     {
-      const size_t ldsg = compare_lds_bytes(N, h->H, h->nd, 4);
+      const size_t ldsg = compare_lds_bytes(N, h->H, h->nd, h->genericWaves);
       HIP_CHECK(h, hipFuncSetAttribute(reinterpret_cast<const void *>(k_compare_generic),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int) ldsg));
     }

@@ -21,7 +21,8 @@ __global__ __launch_bounds__(256) void k_compare_generic(const CompareArgs a)
   const int nd = a.nd;
   float2 *twl = reinterpret_cast<float2 *>(smem);
   int *displ = reinterpret_cast<int *>(smem + (size_t) ((N + 2) & ~1) * 8);
-  float2 *Tall = reinterpret_cast<float2 *>(smem + (size_t) ((N + 2) & ~1) * 8 + 256);
+  const size_t dispBytes = ((size_t) nd * 4 + 255) & ~(size_t) 255; // displacement list, 256-byte granules
+  float2 *Tall = reinterpret_cast<float2 *>(smem + (size_t) ((N + 2) & ~1) * 8 + dispBytes);
   const int wave = __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6)), lane = threadIdx.x & 63;
   float2 *Tl = Tall + (size_t) wave * nd * Hs;
   for (int t = threadIdx.x; t <= N; t += blockDim.x)
@@ -32,7 +33,8 @@ __global__ __launch_bounds__(256) void k_compare_generic(const CompareArgs a)
 
   const int p = blockIdx.x % a.nMaps;
   const int ocg = blockIdx.x / a.nMaps;
-  const int oc_raw = ocg * 4 + wave;
+  const int nWaves = (int) (blockDim.x >> 6); // 4, or fewer when the per-wave T block is large (wide windows)
+  const int oc_raw = ocg * nWaves + wave;
   const bool oc_valid = oc_raw < a.nOC;
   const int oc = oc_valid ? oc_raw : a.nOC - 1;
   const size_t M = (size_t) N * H;

@@ -419,7 +419,7 @@ def test_full_size_slice_against_oracle(full_workload):
                                               # wide windows (the reference's tutorial suggests DISPLACE_CENTER 40 1):
                                               # tiles of the 21- / 31-row window on phase-shifted conv spectra
                                               (64, 20, 1, 1), (128, 40, 1, 1), (224, 20, 1, 1), (100, 40, 2, 1),
-                                              (64, 31, 1, 1), (96, 16, 1, 1), (256, 25, 1, 1), (75, 20, 1, 0),
+                                              (64, 31, 1, 1), (96, 16, 1, 1), (256, 25, 1, 1), (75, 20, 1, 0), (225, 40, 1, 0),
                                               # small windows: the 11-row template (rows <= +-5)
                                               (224, 5, 1, 1), (128, 10, 2, 1), (64, 0, 1, 1), (96, 20, 4, 1),
                                               (80, 4, 2, 1), (224, 10, 2, 1)])
