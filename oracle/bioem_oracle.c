@@ -161,8 +161,8 @@ static void fft_exec(const fft_plan *P, int sign, cpx *x, cpx *y)
     else
     {
       /* generic radix-r butterfly, O(r^2) */
-      cpx av[64], wr[64];
-      if (r > 64)
+      cpx av[1024], wr[1024];
+      if (r > 1024)
       {
         fprintf(stderr, "oracle: prime factor %d too large\n", r);
         abort();

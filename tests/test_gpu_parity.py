@@ -438,6 +438,38 @@ def test_image_sizes_against_oracle(N, maxD, grid, fast, algo):
         W.engine.close()
 
 
+def _random_configs(n, seed):
+    """Seeded random (N, maxD, grid, algo, nEnv, nP, nO) tuples over the whole configuration space of the comparison
+    kernels: every register-FFT length, the Nyquist split, window templates, row strides, tiles, the generic path."""
+    rng = np.random.default_rng(seed)
+    out = []
+    while len(out) < n:
+        N = int(rng.choice([int(rng.integers(8, 140)), int(rng.choice([32, 48, 64, 96, 128, 160, 192, 200, 224, 256]))]))
+        grid = int(rng.choice([1, 1, 1, 2, 3, 4, 5]))
+        maxD = int(rng.integers(0, max(1, N // 2 - 1)))
+        if rng.random() < 0.5:
+            maxD = min(maxD, 12 * grid)
+        if maxD // grid > 45:                      # keep the oracle's share of the run time small
+            continue
+        out.append((N, maxD, grid, int(rng.choice([1, 2])), int(rng.choice([1, 2, 3])), int(rng.integers(1, 6)),
+                    int(rng.integers(1, 8))))
+    return out
+
+
+@pytest.mark.parametrize("cfg", _random_configs(72, 20261004), ids=lambda c: "N%d_d%d_g%d_a%d_e%d_p%d_o%d" % c)
+def test_random_configurations_against_oracle(cfg):
+    from bioem_amd.synthetic import Workload
+    N, maxD, grid, algo, nEnv, nP, nO = cfg
+    W = Workload(N=N, nP=nP, nOrient=nO, nEnv=nEnv, maxD=maxD, grid=grid, algo=algo, npts=150)
+    try:
+        sel = list(range(nP))
+        want, const = oracle_on_workload(W, sel, nO, algo)
+        _, got = run_workload(W, 0, nO)
+        assert_workload_matches(got, want, const, sel)
+    finally:
+        W.engine.close()
+
+
 def _write_mrc(path, data):
     import struct
     ns, nr, nc = data.shape
