@@ -272,7 +272,10 @@ fast_kernel_t fast_kernel_g(int R, bool nyq, int gs)
 
 fast_kernel_t fast_kernel(int winD, int R, bool nyq, int gs)
 {
-  return winD == 5 ? fast_kernel_g<5>(R, nyq, gs) : winD == 10 ? fast_kernel_g<10>(R, nyq, gs) : fast_kernel_g<15>(R, nyq, gs);
+  return winD == 5    ? fast_kernel_g<5>(R, nyq, gs)
+         : winD == 10 ? fast_kernel_g<10>(R, nyq, gs)
+         : winD == 13 ? fast_kernel_g<13>(R, nyq, gs)
+                      : fast_kernel_g<15>(R, nyq, gs);
 }
 
 int launch_compare_fold(bioem_hip_ctx *h, const BatchBuf &bb, int nOC, int orient0, int conv0, int convPerOrient)
@@ -324,6 +327,8 @@ int launch_compare_fold(bioem_hip_ctx *h, const BatchBuf &bb, int nOC, int orien
           hipLaunchKernelGGL(k_nyquist_rows<5>, gridq, dim3(256), 0, h->stream, aw);
         else if (h->winD == 10)
           hipLaunchKernelGGL(k_nyquist_rows<10>, gridq, dim3(256), 0, h->stream, aw);
+        else if (h->winD == 13)
+          hipLaunchKernelGGL(k_nyquist_rows<13>, gridq, dim3(256), 0, h->stream, aw);
         else
           hipLaunchKernelGGL(k_nyquist_rows<15>, gridq, dim3(256), 0, h->stream, aw);
       }
@@ -542,11 +547,24 @@ int bioem_hip_create(bioem_hip_handle *out, int device, const bioem_hip_param_de
   if (N % 2 == 0 && N >= 8 && (mD > 15 || h->nd > 31) && h->nd == 2 * mD + 1 && !getenv("BIOEM_NO_TILES"))
   {
     const int W = h->nd;
-    const int t21 = (W + 20) / 21, t31 = (W + 30) / 31;
-    // launches^2 x the measured cost of one launch of the 21- / 31-row kernel (6.5 / 10.1 ms at 224^2)
-    h->tileT = (t21 * t21 * 6.5 <= t31 * t31 * 10.1) ? 21 : 31;
+    // launches^2 x the measured cost of one launch of the 21- / 27- / 31-row kernel (ms at 224^2)
+    static const int tileRows[3] = {21, 27, 31};
+    static const double tileCost[3] = {6.5, 9.25, 9.9};
+    double best = 1e300;
+    for (int k = 0; k < 3; k++)
+    {
+      const int nt = (W + tileRows[k] - 1) / tileRows[k];
+      if (nt * nt * tileCost[k] < best)
+      {
+        best = nt * nt * tileCost[k];
+        h->tileT = tileRows[k];
+      }
+    }
     if (getenv("BIOEM_TILE_ROWS"))
-      h->tileT = atoi(getenv("BIOEM_TILE_ROWS")) == 31 ? 31 : 21;
+    {
+      const int t = atoi(getenv("BIOEM_TILE_ROWS"));
+      h->tileT = (t == 31 || t == 27) ? t : 21;
+    }
     h->tilesPerAxis = (W + h->tileT - 1) / h->tileT;
     h->winD = (h->tileT - 1) / 2;
     for (int k = 0; k < h->tilesPerAxis; k++)
@@ -561,7 +579,7 @@ int bioem_hip_create(bioem_hip_handle *out, int device, const bioem_hip_param_de
     int R = (N % 32 == 0) ? 32 : (N % 16 == 0) ? 16 : (N % 8 == 0) ? 8 : (N % 4 == 0) ? 4 : 2;
     // 31-row window: a 16-point register FFT keeps the kernel at 3 waves per SIMD (see fast_half_t); sizes that
     // take the Nyquist split (N/2 a multiple of 64) keep R = 32
-    if (h->winD == 15 && R == 32 && fast_half_t(15, 16) && (N / 2) % 64 != 0 && !getenv("BIOEM_WIDE_R32"))
+    if (h->winD > 10 && R == 32 && fast_half_t(15, 16) && (N / 2) % 64 != 0 && !getenv("BIOEM_WIDE_R32"))
       R = 16;
     if (R < 8 && h->gs == 1 && !getenv("BIOEM_POW2_FFT"))
     { // power-of-two part 2 or 4: the largest 2/3/5-smooth even divisor <= 30 (mixed-radix register FFT) wins
