@@ -539,7 +539,7 @@ int bioem_hip_create(bioem_hip_handle *out, int device, const bioem_hip_param_de
   }
   // window template: 2*winD+1 rows, nd <= rows (ALGO 1 with maxD % grid != 0 visits up to 2*(maxD/grid)+2 offsets)
   const int mD = maxD / h->gs;
-  h->winD = (mD <= 5 && h->nd <= 11) ? 5 : (mD <= 10 && h->nd <= 21) ? 10 : 15;
+  h->winD = (mD <= 5 && h->nd <= 11) ? 5 : (mD <= 10 && h->nd <= 21) ? 10 : (mD <= 13 && h->nd <= 27) ? 13 : 15;
   // wide windows: more rows than the 31-row template -> tiles of 21 or 31 rows (window_tiles.hpp); needs the plain
   // symmetric set {gs*m, |m| <= mD}
   h->tileT = 0;
