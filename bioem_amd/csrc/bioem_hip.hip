@@ -16,6 +16,8 @@
 //                          consumed (output pruning), so no radix-7 butterfly is ever needed for N = 224.  The
 //                          transform along ky is a pruned real DFT evaluated from LDS for the window only.
 //                        k_nyquist_rows   the Nyquist column of 128^2 / 256^2 by direct summation
+//   compare_wide.hpp     k_compare_wide   wide windows: 2 or 4 waves per comparison share the column transforms, one
+//                          y-tile of the window per wave (tiles: window_tiles.hpp)
 //   compare_generic.hpp  k_compare_generic  same maths for odd N / very wide windows (direct pruned DFT)
 //   posterior.hpp        calc_logpro / calProb semantics (bioem_algorithm.h:18-142)
 //   fold_kernels.hpp     k_fold_wave, k_fold_angles (k_fold: serial variant): fold the per-comparison partials into the probability block in the
@@ -92,7 +94,8 @@ struct bioem_hip_ctx
   int genericWaves = 4; // waves per block of the generic kernel
   int tileT = 0, tilesPerAxis = 1;
   std::vector<int> tileCenter, tileValid; // per axis tile: centre (in window rows) and number of rows inside the window
-  int *dDispLocal = nullptr, *dTileCenter = nullptr, *dRankOfRow = nullptr;
+  int *dDispLocal = nullptr, *dTileCenter = nullptr, *dTileValid = nullptr, *dRankOfRow = nullptr;
+  int wideWPC = 0; // k_compare_wide: waves per comparison (= y-tiles per launch), 0 = one launch per tile
   float2 *dConvShift = nullptr;
   Partial *dPartTiles = nullptr;
   bool nyq = false;               // Nyquist column handled outside the 64-column blocks (N/2 a multiple of 64)
@@ -166,6 +169,7 @@ struct bioem_hip_ctx
 #include "fft_registers.hpp"
 #include "compare_args.hpp"
 #include "compare_fast.hpp"
+#include "compare_wide.hpp"
 #include "compare_generic.hpp"
 #include "fold_kernels.hpp"
 #include "window_tiles.hpp"
@@ -270,6 +274,24 @@ fast_kernel_t fast_kernel_g(int R, bool nyq, int gs)
          : gs == 3 ? fast_kernel_r<WD, 3>(R, nyq) : fast_kernel_r<WD, 4>(R, nyq);
 }
 
+// k_compare_wide instantiations: R = 32/16/8, row stride 1/2, 2 or 4 waves per comparison
+template <int R>
+fast_kernel_t wide_kernel_r(int gs, int wpc)
+{
+  if (gs == 1)
+    return wpc == 2 ? k_compare_wide<R, 1, 2> : k_compare_wide<R, 1, 4>;
+  return wpc == 2 ? k_compare_wide<R, 2, 2> : k_compare_wide<R, 2, 4>;
+}
+fast_kernel_t wide_kernel(int R, int gs, int wpc)
+{
+  return R == 32 ? wide_kernel_r<32>(gs, wpc) : R == 16 ? wide_kernel_r<16>(gs, wpc) : wide_kernel_r<8>(gs, wpc);
+}
+size_t wide_lds_bytes(int N, int H, int wpc)
+{ // tables + per comparison one T block [21][66] per 64-column block
+  const int nblk = (H + 63) / 64;
+  return (size_t) ((N + 2) & ~1) * 8 + 256 + 1024 + (size_t) (4 / wpc) * nblk * 21 * 66 * 8;
+}
+
 fast_kernel_t fast_kernel(int winD, int R, bool nyq, int gs)
 {
   return winD == 5    ? fast_kernel_g<5>(R, nyq, gs)
@@ -345,6 +367,36 @@ int launch_compare_fold(bioem_hip_ctx *h, const BatchBuf &bb, int nOC, int orien
       at.disp = h->dDispLocal;
       at.nd = h->tileT;
       at.maxD = h->winD * h->gs;
+      if (h->wideWPC)
+      { // per x-tile: conv shifted in x only, then all y-tiles in groups of wideWPC inside k_compare_wide
+        const int wpc = h->wideWPC, cpb = 4 / wpc;
+        const dim3 gridw((unsigned) ((size_t) ((nOC + cpb - 1) / cpb) * h->nMaps));
+        const size_t ldsw = wide_lds_bytes(h->N, h->H, wpc);
+        at.nTiles = nT;
+        at.tileCenter = h->dTileCenter;
+        at.tileValid = h->dTileValid;
+        at.tileStride = tileStride;
+        for (int tx = 0; tx < nT; tx++)
+        {
+          const int sx = h->gs * h->tileCenter[tx];
+          if (sx == 0)
+            at.conv = bb.conv;
+          else
+          {
+            hipLaunchKernelGGL(k_phase_shift, dim3(2048), dim3(256), 0, h->stream, bb.conv, h->dConvShift, total, h->N,
+                               h->H, h->fast, h->N1, sx, 0, h->dTw);
+            at.conv = h->dConvShift;
+          }
+          at.ndx = h->tileValid[tx];
+          at.partials = h->dPartTiles + (size_t) (tx * nT) * tileStride;
+          for (int y0 = 0; y0 < nT; y0 += wpc)
+          {
+            at.yTile0 = y0;
+            hipLaunchKernelGGL(wide_kernel(2 * h->fast, h->gs, wpc), gridw, dim3(256), ldsw, h->stream, at);
+          }
+        }
+      }
+      else
       for (int tx = 0; tx < nT; tx++)
         for (int ty = 0; ty < nT; ty++)
         {
@@ -565,6 +617,13 @@ int bioem_hip_create(bioem_hip_handle *out, int device, const bioem_hip_param_de
       const int t = atoi(getenv("BIOEM_TILE_ROWS"));
       h->tileT = (t == 31 || t == 27) ? t : 21;
     }
+    // k_compare_wide shares the column transforms between the y-tiles of an x-tile: 21-row tiles, power-of-two
+    // register FFT of 8..32, at most two 64-column blocks
+    if (N % 8 == 0 && h->H <= 128 && h->gs <= 2 && !getenv("BIOEM_NO_WIDE") && !getenv("BIOEM_TILE_ROWS"))
+    {
+      h->tileT = 21;
+      h->wideWPC = ((W + 20) / 21 == 2) ? 2 : 4;
+    }
     h->tilesPerAxis = (W + h->tileT - 1) / h->tileT;
     h->winD = (h->tileT - 1) / 2;
     for (int k = 0; k < h->tilesPerAxis; k++)
@@ -684,6 +743,12 @@ int bioem_hip_create(bioem_hip_handle *out, int device, const bioem_hip_param_de
     HIP_CHECK(h, hipMemcpy(h->dRankOfRow, rank.data(), sizeof(int) * rank.size(), hipMemcpyHostToDevice));
     HIP_CHECK(h, hipMalloc(&h->dTileCenter, sizeof(int) * nT));
     HIP_CHECK(h, hipMemcpy(h->dTileCenter, h->tileCenter.data(), sizeof(int) * nT, hipMemcpyHostToDevice));
+    HIP_CHECK(h, hipMalloc(&h->dTileValid, sizeof(int) * nT));
+    HIP_CHECK(h, hipMemcpy(h->dTileValid, h->tileValid.data(), sizeof(int) * nT, hipMemcpyHostToDevice));
+    if (h->wideWPC)
+      HIP_CHECK(h, hipFuncSetAttribute(reinterpret_cast<const void *>(wide_kernel(2 * h->fast, h->gs, h->wideWPC)),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int) wide_lds_bytes(N, h->H, h->wideWPC)));
   }
   h->probBytes = bioem_hip_prob_size(nMaps, nAngles, pd->writeAngles);
   HIP_CHECK(h, hipMalloc(&h->dProb, h->probBytes));
@@ -776,7 +841,7 @@ int bioem_hip_destroy(bioem_hip_handle h)
                   h->dTw,      h->dTwD,     h->dDisp,     h->dLtab,    h->dTwk,     h->dProjReal, h->dTempDen,  h->dRowSpec, h->dSpecRef,
                   h->dScratch, h->dConv,    h->dParams,   h->dPartials, h->dProb,     h->dStage,
                   h->dProjReal2, h->dTempDen2, h->dRowSpec2, h->dSpecRef2, h->dScratch2, h->dConv2, h->dParams2,
-                  h->dTnyq, h->dTwNyq, h->dPartTiles, h->dConvShift, h->dDispLocal, h->dRankOfRow, h->dTileCenter};
+                  h->dTnyq, h->dTwNyq, h->dPartTiles, h->dConvShift, h->dDispLocal, h->dRankOfRow, h->dTileCenter, h->dTileValid};
   for (void *p : ptrs)
     if (p)
       hipFree(p);

@@ -26,6 +26,11 @@ struct CompareArgs
   // window tiles (wide windows are covered by several launches over phase-shifted conv spectra): only the first
   // ndx rows (sorted order) and the first ndy lanes of the displacement list count; nd for an untiled launch
   int ndx, ndy;
+  // k_compare_wide (several y-tiles per launch): first y-tile of the launch, tiles per axis, tile tables (centre in
+  // window rows, rows inside the window), distance between the partial buffers of consecutive tiles
+  int yTile0, nTiles;
+  const int *tileCenter, *tileValid;
+  size_t tileStride;
   PD pd;
 };
 
