@@ -174,6 +174,10 @@ struct bioem_hip_ctx
 #include "fold_kernels.hpp"
 #include "window_tiles.hpp"
 
+#ifndef BIOEM_NYQUIST_SPLIT
+#define BIOEM_NYQUIST_SPLIT 1
+#endif
+
 namespace
 {
 
@@ -275,20 +279,23 @@ fast_kernel_t fast_kernel_g(int R, bool nyq, int gs)
 }
 
 // k_compare_wide instantiations: R = 32/16/8, row stride 1/2, 2 or 4 waves per comparison
-template <int R>
+template <int R, bool NYQ>
 fast_kernel_t wide_kernel_r(int gs, int wpc)
 {
   if (gs == 1)
-    return wpc == 2 ? k_compare_wide<R, 1, 2> : k_compare_wide<R, 1, 4>;
-  return wpc == 2 ? k_compare_wide<R, 2, 2> : k_compare_wide<R, 2, 4>;
+    return wpc == 2 ? k_compare_wide<R, 1, 2, NYQ> : k_compare_wide<R, 1, 4, NYQ>;
+  return wpc == 2 ? k_compare_wide<R, 2, 2, NYQ> : k_compare_wide<R, 2, 4, NYQ>;
 }
-fast_kernel_t wide_kernel(int R, int gs, int wpc)
+fast_kernel_t wide_kernel(int R, int gs, int wpc, bool nyq)
 {
-  return R == 32 ? wide_kernel_r<32>(gs, wpc) : R == 16 ? wide_kernel_r<16>(gs, wpc) : wide_kernel_r<8>(gs, wpc);
+  if (nyq) // N/2 a multiple of 64 implies R = 32
+    return wide_kernel_r<32, true>(gs, wpc);
+  return R == 32 ? wide_kernel_r<32, false>(gs, wpc) : R == 16 ? wide_kernel_r<16, false>(gs, wpc)
+                                                               : wide_kernel_r<8, false>(gs, wpc);
 }
-size_t wide_lds_bytes(int N, int H, int wpc)
+size_t wide_lds_bytes(int N, int H, int wpc, bool nyq)
 { // tables + per comparison one T block [21][66] per 64-column block
-  const int nblk = (H + 63) / 64;
+  const int nblk = nyq ? (H - 1) / 64 : (H + 63) / 64;
   return (size_t) ((N + 2) & ~1) * 8 + 256 + 1024 + (size_t) (4 / wpc) * nblk * 21 * 66 * 8;
 }
 
@@ -371,7 +378,7 @@ int launch_compare_fold(bioem_hip_ctx *h, const BatchBuf &bb, int nOC, int orien
       { // per x-tile: conv shifted in x only, then all y-tiles in groups of wideWPC inside k_compare_wide
         const int wpc = h->wideWPC, cpb = 4 / wpc;
         const dim3 gridw((unsigned) ((size_t) ((nOC + cpb - 1) / cpb) * h->nMaps));
-        const size_t ldsw = wide_lds_bytes(h->N, h->H, wpc);
+        const size_t ldsw = wide_lds_bytes(h->N, h->H, wpc, h->nyq);
         at.nTiles = nT;
         at.tileCenter = h->dTileCenter;
         at.tileValid = h->dTileValid;
@@ -389,10 +396,15 @@ int launch_compare_fold(bioem_hip_ctx *h, const BatchBuf &bb, int nOC, int orien
           }
           at.ndx = h->tileValid[tx];
           at.partials = h->dPartTiles + (size_t) (tx * nT) * tileStride;
+          if (h->nyq)
+          { // Nyquist-column rows of this x-tile (they do not depend on the y-tile)
+            const dim3 gridq((unsigned) (((size_t) (h->nMaps + 15) / 16) * ((nOC + 15) / 16)));
+            hipLaunchKernelGGL(k_nyquist_rows<10>, gridq, dim3(256), 0, h->stream, at);
+          }
           for (int y0 = 0; y0 < nT; y0 += wpc)
           {
             at.yTile0 = y0;
-            hipLaunchKernelGGL(wide_kernel(2 * h->fast, h->gs, wpc), gridw, dim3(256), ldsw, h->stream, at);
+            hipLaunchKernelGGL(wide_kernel(2 * h->fast, h->gs, wpc, h->nyq), gridw, dim3(256), ldsw, h->stream, at);
           }
         }
       }
@@ -619,7 +631,9 @@ int bioem_hip_create(bioem_hip_handle *out, int device, const bioem_hip_param_de
     }
     // k_compare_wide shares the column transforms between the y-tiles of an x-tile: 21-row tiles, power-of-two
     // register FFT of 8..32, at most two 64-column blocks
-    if (N % 8 == 0 && h->H <= 128 && h->gs <= 2 && !getenv("BIOEM_NO_WIDE") && !getenv("BIOEM_TILE_ROWS"))
+    const bool nyqSize = BIOEM_NYQUIST_SPLIT && (N / 2) % 64 == 0; // Nyquist column outside the 64-column blocks
+    const int wideBlocks = nyqSize ? (h->H - 1) / 64 : (h->H + 63) / 64;
+    if (N % 8 == 0 && wideBlocks <= 2 && h->gs <= 2 && !getenv("BIOEM_NO_WIDE") && !getenv("BIOEM_TILE_ROWS"))
     {
       h->tileT = 21;
       h->wideWPC = ((W + 20) / 21 == 2) ? 2 : 4;
@@ -654,9 +668,6 @@ int bioem_hip_create(bioem_hip_handle *out, int device, const bioem_hip_param_de
     h->fast = R / 2;
   }
   h->N1 = h->fast ? N / (2 * h->fast) : 0;
-#ifndef BIOEM_NYQUIST_SPLIT
-#define BIOEM_NYQUIST_SPLIT 1
-#endif
   h->nyq = BIOEM_NYQUIST_SPLIT && h->fast && (N / 2) % 64 == 0;
   // LDS budget check
   {
@@ -746,9 +757,9 @@ int bioem_hip_create(bioem_hip_handle *out, int device, const bioem_hip_param_de
     HIP_CHECK(h, hipMalloc(&h->dTileValid, sizeof(int) * nT));
     HIP_CHECK(h, hipMemcpy(h->dTileValid, h->tileValid.data(), sizeof(int) * nT, hipMemcpyHostToDevice));
     if (h->wideWPC)
-      HIP_CHECK(h, hipFuncSetAttribute(reinterpret_cast<const void *>(wide_kernel(2 * h->fast, h->gs, h->wideWPC)),
+      HIP_CHECK(h, hipFuncSetAttribute(reinterpret_cast<const void *>(wide_kernel(2 * h->fast, h->gs, h->wideWPC, h->nyq)),
                                        hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int) wide_lds_bytes(N, h->H, h->wideWPC)));
+                                       (int) wide_lds_bytes(N, h->H, h->wideWPC, h->nyq)));
   }
   h->probBytes = bioem_hip_prob_size(nMaps, nAngles, pd->writeAngles);
   HIP_CHECK(h, hipMalloc(&h->dProb, h->probBytes));

@@ -16,7 +16,7 @@ namespace
 // Output: one partial per (x-tile, y-tile) with tile-local ids, exactly what the tile-per-launch path writes, so
 // k_merge_tiles is unchanged.
 // ------------------------------------------------------------------------------------------------
-template <int R, int GS, int WPC>
+template <int R, int GS, int WPC, bool NYQ>
 __global__ __launch_bounds__(256, 3) void k_compare_wide(const CompareArgs a)
 {
   constexpr int WD = 10, NW = 2 * WD + 1, NR = 7, TS = 66;
@@ -97,7 +97,8 @@ __global__ __launch_bounds__(256, 3) void k_compare_wide(const CompareArgs a)
   const int rowbase = is_static ? ((wactive ? grp : 0) * NR - mD + WD) * TS : row_of(0);
 
   // ---- column transforms: this wave's share = k1 range [k1a, k1b) of column block myblk ----
-  const int nblk = (H + 63) / 64;  // 1 or 2, divides WPC (host)
+  // 1 or 2 column blocks, dividing WPC (host); NYQ: the Nyquist column comes from k_nyquist_rows (compare_fast.hpp)
+  const int nblk = NYQ ? (H - 1) / 64 : (H + 63) / 64;
   const int C = WPC / nblk;        // waves per column block
   const int myblk = sub / C, part = sub - myblk * C;
   const int k1a = part * N1 / C, k1b = (part + 1) * N1 / C;
@@ -209,6 +210,15 @@ __global__ __launch_bounds__(256, 3) void k_compare_wide(const CompareArgs a)
         rowoff[r] = row_of(r);
       window_accumulate<NR, false, 32, TS>(Tl, twl, N, step, idx0, rowoff, nr, acc);
     }
+  }
+
+  if (NYQ)
+  {
+    const float *tq = a.tnyq + ((size_t) p * a.ldPart + oc) * NW;
+    const float sg = (dy & 1) ? -1.f : 1.f;
+#pragma unroll
+    for (int r = 0; r < NR; r++)
+      acc[r] = fmaf(sg, tq[is_static ? rowbase / TS + r : row_of(r) / TS], acc[r]);
   }
 
   const bioem_hip_param5 q = a.params[oc];
