@@ -4,6 +4,8 @@ for n in 64 96 100 120 128 150 160 180 192 200 224 240 250 256 300 320 384 512; 
   python bench.py --steps 1 --warmup 1 --no-cpu-baseline --pixels $n --orientations 1152 2>/dev/null | tail -1
 done
 for w in "--max-displacement 5" "--max-displacement 10 --grid 2" "--max-displacement 12" "--max-displacement 15" \
-         "--max-displacement 20 --grid 2" "--max-displacement 20" "--write-angles" "--pixels 225"; do
-  python bench.py --steps 1 --warmup 1 --no-cpu-baseline --orientations 1152 $w 2>/dev/null | tail -1
+         "--max-displacement 20 --grid 2" "--max-displacement 20" "--max-displacement 30" "--max-displacement 40" \
+         "--max-displacement 40 --envelopes 4 --defocus 8" "--max-displacement 40 --pixels 128" \
+         "--max-displacement 40 --pixels 256" "--write-angles" "--pixels 225"; do
+  python bench.py --steps 1 --warmup 1 --no-cpu-baseline --orientations 576 $w 2>/dev/null | tail -1
 done
