@@ -224,6 +224,14 @@ def case_table():
                                 kw=[("CTF_B_ENV", [2.0, 300.0, 2]), ("CTF_DEFOCUS", [2.0, 2.0, 1]),
                                     ("CTF_AMPLITUDE", [0.1, 0.1, 1]), ("DISPLACE_CENTER", [40, 1])],
                                 algos=[1, 2], snr=0.05, maxshift=30, seed=122)
+    # G23: the parameter set the reference's tutorial suggests for production runs (doc/index.rst, Param_ProRun):
+    # 4 x 8 CTF grid with Gaussian priors, DISPLACE_CENTER 40 1
+    C["g23_n128_tutorial"] = dict(N=128, px=1.77, nP=2, npts=300, extent=45.0, rad=(2.25, 3.4), orient=("list", 6),
+                                  kw=[("CTF_B_ENV", [2.0, 300.0, 4]), ("CTF_DEFOCUS", [0.5, 4.5, 8]),
+                                      ("CTF_AMPLITUDE", [0.1, 0.1, 1]), ("SIGMA_PRIOR_B_CTF", [50.0]),
+                                      ("SIGMA_PRIOR_DEFOCUS", [0.4]), ("PRIOR_DEFOCUS_CENTER", [2.8]),
+                                      ("DISPLACE_CENTER", [40, 1])],
+                                  algos=[1, 2], snr=0.05, maxshift=30, seed=123)
     only = os.environ.get("BIOEM_GOLDEN_ONLY")  # e.g. "g16,g17": restrict every stage to cases with these prefixes
     if only:
         C = {k: v for k, v in C.items() if any(k.startswith(o + "_") for o in only.split(","))}

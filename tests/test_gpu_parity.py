@@ -247,7 +247,7 @@ def _write_mrc_stack(path, data):
 
 CLI_CASES = ["g10_n64", "g9_n35_odd", "g4_n32_angles", "g5_n32_psf", "g11_n32_eulerlist", "g12_n32_misc",
              "g13_n32_psf_writectf", "g14_n32_mrc", "g15_n32_mrc_nonorm", "g16_n40", "g17_n36", "g18_n50",
-             "g20_n256", "g21_n64_wide20", "g22_n128_wide40"]
+             "g20_n256", "g21_n64_wide20", "g22_n128_wide40", "g23_n128_tutorial"]
 
 
 # (case, orientation shards): BIOEM_SHARDS > 1 runs the CLI's multi-GPU control flow (one engine context and host
