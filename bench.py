@@ -167,7 +167,7 @@ def main():
                    % world},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                     "kernel": "k_compare_fast" if E.fast_path else "k_compare_generic", "launches": int(launches),
+                     "kernel": E.kernel_name, "launches": int(launches),
                      "avg_launch_ms": (kms / launches) if launches else None,
                      "alg_bytes_per_comparison": b_alg,
                      "comparisons_per_launch": (ncomp / launches) if launches else None},

@@ -92,6 +92,7 @@ struct bioem_hip_ctx
   int gs = 1;                     // pixels per window row of the fast kernel (gcd of the displacement offsets)
   // wide windows (more than 31 offsets per axis): tilesPerAxis^2 launches of a tileT-row window (window_tiles.hpp)
   int genericWaves = 4; // waves per block of the generic kernel
+  bool rowsK = false;   // k_compare_rows (odd N, window of at most 31 rows) instead of the generic kernel
   int tileT = 0, tilesPerAxis = 1;
   std::vector<int> tileCenter, tileValid; // per axis tile: centre (in window rows) and number of rows inside the window
   int *dDispLocal = nullptr, *dTileCenter = nullptr, *dTileValid = nullptr, *dRankOfRow = nullptr;
@@ -171,6 +172,7 @@ struct bioem_hip_ctx
 #include "compare_fast.hpp"
 #include "compare_wide.hpp"
 #include "compare_generic.hpp"
+#include "compare_rows.hpp"
 #include "fold_kernels.hpp"
 #include "window_tiles.hpp"
 
@@ -297,6 +299,18 @@ size_t wide_lds_bytes(int N, int H, int wpc, bool nyq)
 { // tables + per comparison one T block [21][66] per 64-column block
   const int nblk = nyq ? (H - 1) / 64 : (H + 63) / 64;
   return (size_t) ((N + 2) & ~1) * 8 + 256 + 1024 + (size_t) (4 / wpc) * nblk * 21 * 66 * 8;
+}
+
+template <int WD>
+fast_kernel_t rows_kernel_g(int gs)
+{
+  return gs == 1 ? k_compare_rows<WD, 1> : gs == 2 ? k_compare_rows<WD, 2> : gs == 3 ? k_compare_rows<WD, 3>
+                                                                                      : k_compare_rows<WD, 4>;
+}
+fast_kernel_t rows_kernel(int winD, int gs)
+{
+  return winD == 5 ? rows_kernel_g<5>(gs) : winD == 10 ? rows_kernel_g<10>(gs) : winD == 13 ? rows_kernel_g<13>(gs)
+                                                                                             : rows_kernel_g<15>(gs);
 }
 
 fast_kernel_t fast_kernel(int winD, int R, bool nyq, int gs)
@@ -431,6 +445,11 @@ int launch_compare_fold(bioem_hip_ctx *h, const BatchBuf &bb, int nOC, int orien
                          nT * nT, tileStride, h->maxOC, nOC, h->nMaps, h->tileT, nT, h->dTileCenter,
                          h->pd.maxDisplaceCenter / h->gs, h->nd, h->dRankOfRow, h->dPartials);
     }
+  }
+  else if (h->rowsK)
+  {
+    const size_t lds = fast_lds_bytes(h->N, 2 * h->winD + 1, 4, false);
+    hipLaunchKernelGGL(rows_kernel(h->winD, h->gs), grid, dim3(256), lds, h->stream, a);
   }
   else
   {
@@ -669,14 +688,18 @@ int bioem_hip_create(bioem_hip_handle *out, int device, const bioem_hip_param_de
   }
   h->N1 = h->fast ? N / (2 * h->fast) : 0;
   h->nyq = BIOEM_NYQUIST_SPLIT && h->fast && (N / 2) % 64 == 0;
+  // no even factor (odd N) but a window of at most 31 rows: k_compare_rows (reference layout, direct column sums,
+  // the fast kernel's T exchange / window / posterior) instead of the generic kernel
+  h->rowsK = !h->fast && N >= 8 && mD <= 15 && h->nd <= 31 && !getenv("BIOEM_NO_ROWS_KERNEL");
   // LDS budget check
   {
     // generic kernel: as many waves per block (4, 2, 1) as its per-wave T block [nd][H] lets fit
     h->genericWaves = 4;
     while (!h->fast && h->genericWaves > 1 && compare_lds_bytes(N, h->H, h->nd, h->genericWaves) > 160 * 1024)
       h->genericWaves >>= 1;
-    const size_t lds = h->fast ? fast_lds_bytes(N, 2 * h->winD + 1, 4, fast_half_t(h->winD, 2 * h->fast))
-                               : compare_lds_bytes(N, h->H, h->nd, h->genericWaves);
+    const size_t lds = h->fast    ? fast_lds_bytes(N, 2 * h->winD + 1, 4, fast_half_t(h->winD, 2 * h->fast))
+                       : h->rowsK ? fast_lds_bytes(N, 2 * h->winD + 1, 4, false)
+                                  : compare_lds_bytes(N, h->H, h->nd, h->genericWaves);
     if (lds > 160 * 1024)
     {
       h->err = "configuration exceeds the 160 KiB LDS budget of the comparison kernel";
@@ -685,6 +708,10 @@ int bioem_hip_create(bioem_hip_handle *out, int device, const bioem_hip_param_de
     if (h->fast)
       HIP_CHECK(h, hipFuncSetAttribute(reinterpret_cast<const void *>(fast_kernel(h->winD, 2 * h->fast, h->nyq, h->gs)),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
+    else if (h->rowsK)
+      HIP_CHECK(h, hipFuncSetAttribute(reinterpret_cast<const void *>(rows_kernel(h->winD, h->gs)),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int) fast_lds_bytes(N, 2 * h->winD + 1, 4, false)));
     else
     {
       const size_t ldsg = compare_lds_bytes(N, h->H, h->nd, h->genericWaves);
@@ -804,11 +831,12 @@ int bioem_hip_create(bioem_hip_handle *out, int device, const bioem_hip_param_de
     }
     HIP_CHECK(h, hipMemcpy(h->dLtab, lt.data(), sizeof(double2) * 64, hipMemcpyHostToDevice));
   }
-  if (h->fast)
+  if (h->fast || h->rowsK)
   {
     const int NW = 2 * h->winD + 1;
-    std::vector<float2> twk((size_t) h->N1 * NW);
-    for (int k1 = 0; k1 < h->N1; k1++)
+    const int nK1 = h->rowsK ? N : h->N1; // k_compare_rows: a "register FFT" of length 1, one table row per kx
+    std::vector<float2> twk((size_t) nK1 * NW);
+    for (int k1 = 0; k1 < nK1; k1++)
       for (int d = -h->winD; d <= h->winD; d++)
       {
         const double ang = 2.0 * M_PI * (double) ((((long long) d * h->gs * k1) % N + N) % N) / (double) N;
@@ -1235,6 +1263,15 @@ int bioem_hip_reset_kernel_stats(bioem_hip_handle h)
 }
 
 int bioem_hip_uses_fast_path(bioem_hip_handle h) { return h && h->fast ? 1 : 0; }
+
+const char *bioem_hip_kernel_name(bioem_hip_handle h)
+{
+  if (!h)
+    return "";
+  if (h->fast)
+    return (h->tileT && h->wideWPC) ? "k_compare_wide" : "k_compare_fast";
+  return h->rowsK ? "k_compare_rows" : "k_compare_generic";
+}
 
 int bioem_hip_r2c(int device, int N, int nImg, const float *in, float *out)
 {

@@ -68,6 +68,8 @@ def load_library():
     L.bioem_hip_kernel_stats.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]
     L.bioem_hip_reset_kernel_stats.argtypes = [vp]
     L.bioem_hip_uses_fast_path.argtypes = [vp]
+    L.bioem_hip_kernel_name.argtypes = [vp]
+    L.bioem_hip_kernel_name.restype = C.c_char_p
     L.bioem_hip_synchronize.argtypes = [vp]
     L.bioem_hip_r2c.argtypes = [ci, ci, ci, vp, vp]
     _lib = L
@@ -81,6 +83,7 @@ EXPORTS = ["bioem_hip_device_count", "bioem_hip_create", "bioem_hip_destroy", "b
            "bioem_hip_project_convolve_compare", "bioem_hip_finish_run", "bioem_hip_merge_host",
            "bioem_hip_debug_projection", "bioem_hip_debug_convolution", "bioem_hip_debug_particles",
            "bioem_hip_kernel_stats", "bioem_hip_reset_kernel_stats", "bioem_hip_uses_fast_path",
+           "bioem_hip_kernel_name",
            "bioem_hip_synchronize", "bioem_hip_r2c"]
 
 
@@ -138,6 +141,10 @@ class Engine:
     @property
     def fast_path(self):
         return bool(self.L.bioem_hip_uses_fast_path(self.h))
+
+    @property
+    def kernel_name(self):
+        return self.L.bioem_hip_kernel_name(self.h).decode()
 
     def upload_particles(self, refFFT, sumRef, sumsqRef):
         refFFT = np.ascontiguousarray(refFFT, dtype=np.float32)

@@ -424,6 +424,9 @@ def test_full_size_slice_against_oracle(full_workload):
                                               (64, 20, 1, 1), (128, 40, 1, 1), (224, 20, 1, 1), (100, 40, 2, 1),
                                               (64, 31, 1, 1), (96, 16, 1, 1), (256, 25, 1, 1), (75, 20, 1, 0), (225, 40, 1, 0),
                                               (320, 20, 1, 1), (384, 40, 2, 1), (272, 16, 1, 1),
+                                              # odd sizes: k_compare_rows (direct column sums + the fast kernel's back half)
+                                              (225, 10, 1, 0), (127, 12, 1, 0), (51, 15, 1, 0), (99, 10, 2, 0),
+                                              (33, 4, 1, 0), (129, 20, 2, 0), (9, 2, 1, 0),
                                               # small windows: the 11-row template (rows <= +-5)
                                               (224, 5, 1, 1), (128, 10, 2, 1), (64, 0, 1, 1), (96, 20, 4, 1),
                                               (80, 4, 2, 1), (224, 10, 2, 1)])
