@@ -358,11 +358,16 @@ int launch_compare_fold(bioem_hip_ctx *h, const BatchBuf &bb, int nOC, int orien
     return 1;
   }
   HIP_CHECK(h, hipEventRecord(e0, h->stream));
-  if (h->fast)
+  if (h->fast || h->rowsK)
   {
     const int NW = 2 * h->winD + 1;
-    const size_t lds = fast_lds_bytes(h->N, NW, 4, fast_half_t(h->winD, 2 * h->fast));
+    const size_t lds = fast_lds_bytes(h->N, NW, 4, h->fast ? fast_half_t(h->winD, 2 * h->fast) : false);
     auto launch_window = [&](const CompareArgs &aw) {
+      if (h->rowsK)
+      {
+        hipLaunchKernelGGL(rows_kernel(h->winD, h->gs), grid, dim3(256), lds, h->stream, aw);
+        return;
+      }
       if (h->nyq)
       {
         const dim3 gridq((unsigned) (((size_t) (h->nMaps + 15) / 16) * ((nOC + 15) / 16)));
@@ -445,11 +450,6 @@ int launch_compare_fold(bioem_hip_ctx *h, const BatchBuf &bb, int nOC, int orien
                          nT * nT, tileStride, h->maxOC, nOC, h->nMaps, h->tileT, nT, h->dTileCenter,
                          h->pd.maxDisplaceCenter / h->gs, h->nd, h->dRankOfRow, h->dPartials);
     }
-  }
-  else if (h->rowsK)
-  {
-    const size_t lds = fast_lds_bytes(h->N, 2 * h->winD + 1, 4, false);
-    hipLaunchKernelGGL(rows_kernel(h->winD, h->gs), grid, dim3(256), lds, h->stream, a);
   }
   else
   {
@@ -627,7 +627,7 @@ int bioem_hip_create(bioem_hip_handle *out, int device, const bioem_hip_param_de
   // symmetric set {gs*m, |m| <= mD}
   h->tileT = 0;
   h->tilesPerAxis = 1;
-  if (N % 2 == 0 && N >= 8 && (mD > 15 || h->nd > 31) && h->nd == 2 * mD + 1 && !getenv("BIOEM_NO_TILES"))
+  if (N >= 8 && (mD > 15 || h->nd > 31) && h->nd == 2 * mD + 1 && !getenv("BIOEM_NO_TILES"))
   {
     const int W = h->nd;
     // launches^2 x the measured cost of one launch of the 21- / 27- / 31-row kernel (ms at 224^2)
@@ -690,7 +690,13 @@ int bioem_hip_create(bioem_hip_handle *out, int device, const bioem_hip_param_de
   h->nyq = BIOEM_NYQUIST_SPLIT && h->fast && (N / 2) % 64 == 0;
   // no even factor (odd N) but a window of at most 31 rows: k_compare_rows (reference layout, direct column sums,
   // the fast kernel's T exchange / window / posterior) instead of the generic kernel
-  h->rowsK = !h->fast && N >= 8 && mD <= 15 && h->nd <= 31 && !getenv("BIOEM_NO_ROWS_KERNEL");
+  h->rowsK = !h->fast && N >= 8 && (h->tileT || (mD <= 15 && h->nd <= 31)) && !getenv("BIOEM_NO_ROWS_KERNEL");
+  if (h->tileT && !h->fast && !h->rowsK)
+  { // no tiled kernel available after all: plain generic kernel on the whole window
+    h->tileT = 0;
+    h->tilesPerAxis = 1;
+    h->wideWPC = 0;
+  }
   // LDS budget check
   {
     // generic kernel: as many waves per block (4, 2, 1) as its per-wave T block [nd][H] lets fit

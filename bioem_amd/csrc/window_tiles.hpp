@@ -22,14 +22,23 @@ __global__ void k_phase_shift(const float2 *__restrict__ src, float2 *__restrict
   const size_t M = (size_t) N * H;
   for (size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t) gridDim.x * blockDim.x)
   {
-    // comparison layout: ((k1*R2 + k2p)*H + ky)*2 + (k2 & 1),  kx = N1*k2 + k1
     const size_t e = i % M;
-    const int par = (int) (e & 1);
-    const size_t q = e >> 1;
-    const int ky = (int) (q % H);
-    const int rp = (int) (q / H);
-    const int k1 = rp / R2, k2 = 2 * (rp % R2) + par;
-    const long long kx = (long long) N1 * k2 + k1;
+    int ky;
+    long long kx;
+    if (R2 == 0)
+    { // reference layout kx*H + ky (k_compare_rows)
+      ky = (int) (e % H);
+      kx = (long long) (e / H);
+    }
+    else
+    { // comparison layout: ((k1*R2 + k2p)*H + ky)*2 + (k2 & 1),  kx = N1*k2 + k1
+      const int par = (int) (e & 1);
+      const size_t q = e >> 1;
+      ky = (int) (q % H);
+      const int rp = (int) (q / H);
+      const int k1 = rp / R2, k2 = 2 * (rp % R2) + par;
+      kx = (long long) N1 * k2 + k1;
+    }
     const int t = (int) (((kx * sx + (long long) ky * sy) % N + N) % N);
     const float2 w = tw[t], c = src[i];
     dst[i] = make_float2(fmaf(c.x, w.x, -(c.y * w.y)), fmaf(c.x, w.y, c.y * w.x));

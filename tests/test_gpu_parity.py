@@ -426,7 +426,7 @@ def test_full_size_slice_against_oracle(full_workload):
                                               (320, 20, 1, 1), (384, 40, 2, 1), (272, 16, 1, 1),
                                               # odd sizes: k_compare_rows (direct column sums + the fast kernel's back half)
                                               (225, 10, 1, 0), (127, 12, 1, 0), (51, 15, 1, 0), (99, 10, 2, 0),
-                                              (33, 4, 1, 0), (129, 20, 2, 0), (9, 2, 1, 0),
+                                              (33, 4, 1, 0), (129, 20, 2, 0), (9, 2, 1, 0), (125, 40, 1, 0), (75, 16, 1, 0),
                                               # small windows: the 11-row template (rows <= +-5)
                                               (224, 5, 1, 1), (128, 10, 2, 1), (64, 0, 1, 1), (96, 20, 4, 1),
                                               (80, 4, 2, 1), (224, 10, 2, 1)])
