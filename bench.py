@@ -49,7 +49,7 @@ def cpu_baseline(W, n_orient, n_threads):
               W.nCTF, W.refCTF.ctypes.data, W.ctfParam.ctypes.data, nP, refFFT.ctypes.data, sumRef.ctypes.data,
               sumsqRef.ctypes.data, 0, n_orient, pmap.ctypes.data, None)
     dt = time.time() - t0
-    return n_orient * W.nCTF * nP / dt, dt
+    return n_orient * W.nCTF * nP / dt, dt, pmap, orc.logp_constant(pd)
 
 
 def main():
@@ -187,10 +187,24 @@ def main():
         sys.path.insert(0, os.path.join(ROOT, "oracle"))
         import oracle as orc
         nthreads = orc.usable_cpus(cap=16)  # the GPU box's CPU share for one GPU
-        v, secs = cpu_baseline(W, args.cpu_orientations, nthreads)
+        nco = min(args.cpu_orientations, W.nOrient)
+        v, secs, want, const = cpu_baseline(W, nco, nthreads)
         out["cpu_baseline"] = {"value": v, "unit": "comparisons/s", "cores": nthreads, "kind": "port",
                                "sample": "%d orientations x %d CTF x %d particles of the same workload (%.1f s)"
-                               % (args.cpu_orientations, W.nCTF, W.nP, secs)}
+                               % (nco, W.nCTF, W.nP, secs)}
+        # the checker's second job: the HIP path on the SAME sample against the oracle (untimed)
+        raw, got, _ = new_prob_block(nMaps, W.nOrient, int(args.write_angles))
+        E.start_run(raw)
+        E.project_convolve_compare(0, nco)
+        E.finish_run(raw)
+        la = np.log(got["Total"]) + got["Constoadd"] + const
+        lb = np.log(want["Total"]) + want["Constoadd"] + const
+        same = ((got["orient"] == want["orient"]) & (got["conv"] == want["conv"]) &
+                (got["cent_x"] == want["cent_x"]) & (got["cent_y"] == want["cent_y"]))
+        out["parity"] = {"against": "CPU oracle on the cpu_baseline sample", "particles": int(nMaps),
+                         "max_abs_dlogp": float(np.abs(la - lb).max()),
+                         "max_rel_dlogp": float((np.abs(la - lb) / np.abs(lb)).max()),
+                         "argmax_mismatches": int((~same).sum()), "tolerance_rel": 1e-4}
     if rank == 0:
         print(json.dumps(out))
     if world > 1:
