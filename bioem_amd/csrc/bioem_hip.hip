@@ -18,6 +18,8 @@
 //                        k_nyquist_rows   the Nyquist column of 128^2 / 256^2 by direct summation
 //   compare_wide.hpp     k_compare_wide   wide windows: 2 or 4 waves per comparison share the column transforms, one
 //                          y-tile of the window per wave (tiles: window_tiles.hpp)
+//   compare_rows.hpp     k_compare_oddfft / k_compare_rows  odd image sizes: register FFT of odd length (3..25) over the
+//                          reference layout, or direct column sums when N has no factor 3 or 5
 //   compare_generic.hpp  k_compare_generic  same maths for odd N / very wide windows (direct pruned DFT)
 //   posterior.hpp        calc_logpro / calProb semantics (bioem_algorithm.h:18-142)
 //   fold_kernels.hpp     k_fold_wave, k_fold_angles (k_fold: serial variant): fold the per-comparison partials into the probability block in the
@@ -92,7 +94,8 @@ struct bioem_hip_ctx
   int gs = 1;                     // pixels per window row of the fast kernel (gcd of the displacement offsets)
   // wide windows (more than 31 offsets per axis): tilesPerAxis^2 launches of a tileT-row window (window_tiles.hpp)
   int genericWaves = 4; // waves per block of the generic kernel
-  bool rowsK = false;   // k_compare_rows (odd N, window of at most 31 rows) instead of the generic kernel
+  bool rowsK = false;   // k_compare_rows / k_compare_oddfft (odd N) instead of the generic kernel
+  int oddR = 0;         // k_compare_oddfft: register-FFT length (3, 5, 9, 15, 25) dividing an odd N; 0 = direct sums
   int tileT = 0, tilesPerAxis = 1;
   std::vector<int> tileCenter, tileValid; // per axis tile: centre (in window rows) and number of rows inside the window
   int *dDispLocal = nullptr, *dTileCenter = nullptr, *dTileValid = nullptr, *dRankOfRow = nullptr;
@@ -307,8 +310,18 @@ fast_kernel_t rows_kernel_g(int gs)
   return gs == 1 ? k_compare_rows<WD, 1> : gs == 2 ? k_compare_rows<WD, 2> : gs == 3 ? k_compare_rows<WD, 3>
                                                                                       : k_compare_rows<WD, 4>;
 }
-fast_kernel_t rows_kernel(int winD, int gs)
+template <int WD>
+fast_kernel_t oddfft_kernel_r(int R)
 {
+  return R == 25 ? k_compare_oddfft<WD, 25> : R == 15 ? k_compare_oddfft<WD, 15> : R == 9 ? k_compare_oddfft<WD, 9>
+         : R == 5 ? k_compare_oddfft<WD, 5> : k_compare_oddfft<WD, 3>;
+}
+// odd N: register FFT of odd length R over the reference layout if R > 0 (unit row stride), else direct column sums
+fast_kernel_t rows_kernel(int winD, int gs, int oddR = 0)
+{
+  if (oddR)
+    return winD == 5 ? oddfft_kernel_r<5>(oddR) : winD == 10 ? oddfft_kernel_r<10>(oddR)
+           : winD == 13 ? oddfft_kernel_r<13>(oddR) : oddfft_kernel_r<15>(oddR);
   return winD == 5 ? rows_kernel_g<5>(gs) : winD == 10 ? rows_kernel_g<10>(gs) : winD == 13 ? rows_kernel_g<13>(gs)
                                                                                              : rows_kernel_g<15>(gs);
 }
@@ -365,7 +378,7 @@ int launch_compare_fold(bioem_hip_ctx *h, const BatchBuf &bb, int nOC, int orien
     auto launch_window = [&](const CompareArgs &aw) {
       if (h->rowsK)
       {
-        hipLaunchKernelGGL(rows_kernel(h->winD, h->gs), grid, dim3(256), lds, h->stream, aw);
+        hipLaunchKernelGGL(rows_kernel(h->winD, h->gs, h->oddR), grid, dim3(256), lds, h->stream, aw);
         return;
       }
       if (h->nyq)
@@ -691,6 +704,17 @@ int bioem_hip_create(bioem_hip_handle *out, int device, const bioem_hip_param_de
   // no even factor (odd N) but a window of at most 31 rows: k_compare_rows (reference layout, direct column sums,
   // the fast kernel's T exchange / window / posterior) instead of the generic kernel
   h->rowsK = !h->fast && N >= 8 && (h->tileT || (mD <= 15 && h->nd <= 31)) && !getenv("BIOEM_NO_ROWS_KERNEL");
+  if (h->rowsK && h->gs == 1 && !getenv("BIOEM_NO_ODD_FFT"))
+  {
+    static const int oddLens[] = {25, 15, 9, 5, 3};
+    for (int r : oddLens)
+      if (N % r == 0)
+      {
+        h->oddR = r;
+        h->N1 = N / r;
+        break;
+      }
+  }
   if (h->tileT && !h->fast && !h->rowsK)
   { // no tiled kernel available after all: plain generic kernel on the whole window
     h->tileT = 0;
@@ -715,7 +739,7 @@ int bioem_hip_create(bioem_hip_handle *out, int device, const bioem_hip_param_de
       HIP_CHECK(h, hipFuncSetAttribute(reinterpret_cast<const void *>(fast_kernel(h->winD, 2 * h->fast, h->nyq, h->gs)),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
     else if (h->rowsK)
-      HIP_CHECK(h, hipFuncSetAttribute(reinterpret_cast<const void *>(rows_kernel(h->winD, h->gs)),
+      HIP_CHECK(h, hipFuncSetAttribute(reinterpret_cast<const void *>(rows_kernel(h->winD, h->gs, h->oddR)),
                                        hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int) fast_lds_bytes(N, 2 * h->winD + 1, 4, false)));
     else
@@ -840,7 +864,8 @@ int bioem_hip_create(bioem_hip_handle *out, int device, const bioem_hip_param_de
   if (h->fast || h->rowsK)
   {
     const int NW = 2 * h->winD + 1;
-    const int nK1 = h->rowsK ? N : h->N1; // k_compare_rows: a "register FFT" of length 1, one table row per kx
+    // k_compare_rows: a "register FFT" of length 1, one table row per kx; k_compare_oddfft: N1 = N / oddR
+    const int nK1 = (h->rowsK && !h->oddR) ? N : h->N1;
     std::vector<float2> twk((size_t) nK1 * NW);
     for (int k1 = 0; k1 < nK1; k1++)
       for (int d = -h->winD; d <= h->winD; d++)
@@ -1276,7 +1301,7 @@ const char *bioem_hip_kernel_name(bioem_hip_handle h)
     return "";
   if (h->fast)
     return (h->tileT && h->wideWPC) ? "k_compare_wide" : "k_compare_fast";
-  return h->rowsK ? "k_compare_rows" : "k_compare_generic";
+  return h->rowsK ? (h->oddR ? "k_compare_oddfft" : "k_compare_rows") : "k_compare_generic";
 }
 
 int bioem_hip_r2c(int device, int N, int nImg, const float *in, float *out)

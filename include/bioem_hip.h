@@ -150,7 +150,7 @@ int bioem_hip_reset_kernel_stats(bioem_hip_handle h);
 /* 1 if the LDS-FFT fast path is used for this configuration, 0 for the generic pruned-DFT path */
 int bioem_hip_uses_fast_path(bioem_hip_handle h);
 /* name of the comparison kernel this configuration runs: "k_compare_fast", "k_compare_wide" (tiled wide window),
- * "k_compare_rows" (odd image size) or "k_compare_generic" */
+ * "k_compare_oddfft" / "k_compare_rows" (odd image size with / without a factor 3 or 5) or "k_compare_generic" */
 const char *bioem_hip_kernel_name(bioem_hip_handle h);
 int bioem_hip_synchronize(bioem_hip_handle h);
 
