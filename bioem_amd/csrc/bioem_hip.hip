@@ -283,7 +283,8 @@ fast_kernel_t fast_kernel_g(int R, bool nyq, int gs)
          : gs == 3 ? fast_kernel_r<WD, 3>(R, nyq) : fast_kernel_r<WD, 4>(R, nyq);
 }
 
-// k_compare_wide instantiations: R = 32/16/8, row stride 1/2, 2 or 4 waves per comparison
+// k_compare_wide instantiations: every register-FFT length of the fast kernel, row stride 1/2 (mixed radix: 1), 2 or 4
+// waves per comparison
 template <int R, bool NYQ>
 fast_kernel_t wide_kernel_r(int gs, int wpc)
 {
@@ -295,8 +296,21 @@ fast_kernel_t wide_kernel(int R, int gs, int wpc, bool nyq)
 {
   if (nyq) // N/2 a multiple of 64 implies R = 32
     return wide_kernel_r<32, true>(gs, wpc);
-  return R == 32 ? wide_kernel_r<32, false>(gs, wpc) : R == 16 ? wide_kernel_r<16, false>(gs, wpc)
-                                                               : wide_kernel_r<8, false>(gs, wpc);
+  switch (R)
+  {
+  case 32: return wide_kernel_r<32, false>(gs, wpc);
+  case 16: return wide_kernel_r<16, false>(gs, wpc);
+  case 8: return wide_kernel_r<8, false>(gs, wpc);
+  case 4: return wide_kernel_r<4, false>(gs, wpc);
+  case 2: return wide_kernel_r<2, false>(gs, wpc);
+  // mixed-radix lengths are only chosen with a unit row stride
+  case 30: return wpc == 2 ? k_compare_wide<30, 1, 2, false> : k_compare_wide<30, 1, 4, false>;
+  case 20: return wpc == 2 ? k_compare_wide<20, 1, 2, false> : k_compare_wide<20, 1, 4, false>;
+  case 18: return wpc == 2 ? k_compare_wide<18, 1, 2, false> : k_compare_wide<18, 1, 4, false>;
+  case 12: return wpc == 2 ? k_compare_wide<12, 1, 2, false> : k_compare_wide<12, 1, 4, false>;
+  case 10: return wpc == 2 ? k_compare_wide<10, 1, 2, false> : k_compare_wide<10, 1, 4, false>;
+  default: return wpc == 2 ? k_compare_wide<6, 1, 2, false> : k_compare_wide<6, 1, 4, false>;
+  }
 }
 size_t wide_lds_bytes(int N, int H, int wpc, bool nyq)
 { // tables + per comparison one T block [21][66] per 64-column block
@@ -662,10 +676,10 @@ int bioem_hip_create(bioem_hip_handle *out, int device, const bioem_hip_param_de
       h->tileT = (t == 31 || t == 27) ? t : 21;
     }
     // k_compare_wide shares the column transforms between the y-tiles of an x-tile: 21-row tiles, power-of-two
-    // register FFT of 8..32, at most two 64-column blocks
+    // at most two 64-column blocks
     const bool nyqSize = BIOEM_NYQUIST_SPLIT && (N / 2) % 64 == 0; // Nyquist column outside the 64-column blocks
     const int wideBlocks = nyqSize ? (h->H - 1) / 64 : (h->H + 63) / 64;
-    if (N % 8 == 0 && wideBlocks <= 2 && h->gs <= 2 && !getenv("BIOEM_NO_WIDE") && !getenv("BIOEM_TILE_ROWS"))
+    if (N % 2 == 0 && wideBlocks <= 2 && h->gs <= 2 && !getenv("BIOEM_NO_WIDE") && !getenv("BIOEM_TILE_ROWS"))
     {
       h->tileT = 21;
       h->wideWPC = ((W + 20) / 21 == 2) ? 2 : 4;

@@ -12,7 +12,8 @@ namespace
 // comparison: the column transforms are split between them (by column block, then by k1 range), the partial T
 // blocks are combined in LDS in a fixed wave order (deterministic), and then every wave runs the window pass and the
 // posterior of ITS y-tile on the shared T.  Per comparison and x-tile the operand stream and the register FFTs are
-// paid once instead of once per y-tile.  21-row tiles, R = 32/16/8, up to two 64-column blocks.
+// paid once instead of once per y-tile.  21-row tiles, any register-FFT length of the fast kernel, up to two
+// 64-column blocks.
 // Output: one partial per (x-tile, y-tile) with tile-local ids, exactly what the tile-per-launch path writes, so
 // k_merge_tiles is unchanged.
 // ------------------------------------------------------------------------------------------------
@@ -21,7 +22,8 @@ __global__ __launch_bounds__(256, 3) void k_compare_wide(const CompareArgs a)
 {
   constexpr int WD = 10, NW = 2 * WD + 1, NR = 7, TS = 66;
   constexpr int R2 = R / 2;
-  constexpr int RD = (R2 % 4 == 0) ? 4 : (R2 % 2 == 0) ? 2 : 1;
+  // ring depth: divides R2 (mixed-radix lengths: R2 = 3, 5, 6, 9, 10, 15)
+  constexpr int RD = (R2 % 4 == 0) ? 4 : (R2 % 5 == 0) ? 5 : (R2 % 3 == 0) ? 3 : (R2 % 2 == 0) ? 2 : 1;
   constexpr int CPB = 4 / WPC; // comparisons per block
   extern __shared__ __align__(16) unsigned char smem[];
   const int N = a.N, H = a.H, N1 = a.N1;

@@ -423,7 +423,8 @@ def test_full_size_slice_against_oracle(full_workload):
                                               # tiles of the 21- / 31-row window on phase-shifted conv spectra
                                               (64, 20, 1, 1), (128, 40, 1, 1), (224, 20, 1, 1), (100, 40, 2, 1),
                                               (64, 31, 1, 1), (96, 16, 1, 1), (256, 25, 1, 1), (75, 20, 1, 0), (225, 40, 1, 0),
-                                              (320, 20, 1, 1), (384, 40, 2, 1), (272, 16, 1, 1),
+                                              (320, 20, 1, 1), (384, 40, 2, 1), (272, 16, 1, 1), (100, 40, 1, 1), (180, 20, 1, 1), (250, 30, 1, 1),
+                                              (150, 16, 1, 1), (44, 20, 1, 1), (60, 25, 1, 1),
                                               # odd sizes: k_compare_rows (direct column sums + the fast kernel's back half)
                                               (225, 10, 1, 0), (127, 12, 1, 0), (51, 15, 1, 0), (99, 10, 2, 0),
                                               (33, 4, 1, 0), (129, 20, 2, 0), (9, 2, 1, 0), (125, 40, 1, 0), (75, 16, 1, 0),
