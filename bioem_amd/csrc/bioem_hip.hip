@@ -676,13 +676,14 @@ int bioem_hip_create(bioem_hip_handle *out, int device, const bioem_hip_param_de
       h->tileT = (t == 31 || t == 27) ? t : 21;
     }
     // k_compare_wide shares the column transforms between the y-tiles of an x-tile: 21-row tiles, power-of-two
-    // at most two 64-column blocks
+    // at most four 64-column blocks
     const bool nyqSize = BIOEM_NYQUIST_SPLIT && (N / 2) % 64 == 0; // Nyquist column outside the 64-column blocks
     const int wideBlocks = nyqSize ? (h->H - 1) / 64 : (h->H + 63) / 64;
-    if (N % 2 == 0 && wideBlocks <= 2 && h->gs <= 2 && !getenv("BIOEM_NO_WIDE") && !getenv("BIOEM_TILE_ROWS"))
+    if (N % 2 == 0 && wideBlocks <= 4 && h->gs <= 2 && !getenv("BIOEM_NO_WIDE") && !getenv("BIOEM_TILE_ROWS"))
     {
       h->tileT = 21;
-      h->wideWPC = ((W + 20) / 21 == 2) ? 2 : 4;
+      // waves per comparison: one per y-tile, and at least one per column block
+      h->wideWPC = ((W + 20) / 21 == 2 && wideBlocks <= 2) ? 2 : 4;
     }
     h->tilesPerAxis = (W + h->tileT - 1) / h->tileT;
     h->winD = (h->tileT - 1) / 2;

@@ -12,8 +12,8 @@ namespace
 // comparison: the column transforms are split between them (by column block, then by k1 range), the partial T
 // blocks are combined in LDS in a fixed wave order (deterministic), and then every wave runs the window pass and the
 // posterior of ITS y-tile on the shared T.  Per comparison and x-tile the operand stream and the register FFTs are
-// paid once instead of once per y-tile.  21-row tiles, any register-FFT length of the fast kernel, up to two
-// 64-column blocks.
+// paid once instead of once per y-tile.  21-row tiles, any register-FFT length of the fast kernel, as many
+// 64-column blocks as waves per comparison.
 // Output: one partial per (x-tile, y-tile) with tile-local ids, exactly what the tile-per-launch path writes, so
 // k_merge_tiles is unchanged.
 // ------------------------------------------------------------------------------------------------
@@ -99,11 +99,15 @@ __global__ __launch_bounds__(256, 3) void k_compare_wide(const CompareArgs a)
   const int rowbase = is_static ? ((wactive ? grp : 0) * NR - mD + WD) * TS : row_of(0);
 
   // ---- column transforms: this wave's share = k1 range [k1a, k1b) of column block myblk ----
-  // 1 or 2 column blocks, dividing WPC (host); NYQ: the Nyquist column comes from k_nyquist_rows (compare_fast.hpp)
+  // nblk <= WPC column blocks (host); NYQ: the Nyquist column comes from k_nyquist_rows (compare_fast.hpp).  If nblk
+  // divides WPC, C = WPC / nblk waves share a block by k1 range; otherwise (3 blocks on 4 waves) every wave takes
+  // one whole block and the last wave sits the column phase out
   const int nblk = NYQ ? (H - 1) / 64 : (H + 63) / 64;
-  const int C = WPC / nblk;        // waves per column block
-  const int myblk = sub / C, part = sub - myblk * C;
-  const int k1a = part * N1 / C, k1b = (part + 1) * N1 / C;
+  const bool split = (WPC % nblk) == 0;
+  const int C = split ? WPC / nblk : 1; // waves per column block
+  const int myblk = split ? sub / C : sub, part = split ? sub - myblk * C : 0;
+  const bool owns = myblk < nblk;
+  const int k1a = owns ? part * N1 / C : 0, k1b = owns ? (part + 1) * N1 / C : 0;
   const unsigned rowbytes = (unsigned) H * 16u;
   const int ky = myblk * 64 + lane;
   const int kyc = ky < H ? ky : H - 1;
@@ -176,7 +180,7 @@ __global__ __launch_bounds__(256, 3) void k_compare_wide(const CompareArgs a)
     float2 *Tb = Tall + (size_t) ((cmp * nblk + myblk) * NW) * TS;
     for (int turn = 0; turn < C; turn++)
     {
-      if (part == turn)
+      if (part == turn && owns)
       {
 #pragma unroll
         for (int d = 0; d < NW; d++)
