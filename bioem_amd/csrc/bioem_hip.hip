@@ -151,13 +151,26 @@ struct bioem_hip_ctx
   hipEvent_t cmpDone[2] = {nullptr, nullptr};
   bool cmpPending[2] = {false, false};
 
-  // compat entry staging
-  float2 *hStage = nullptr;
-  float2 *dStage = nullptr;
-  bioem_hip_param5 *hStageP = nullptr;
-  int stageConv = 0;
-  hipEvent_t slotEvent[2] = {nullptr, nullptr};
-  bool slotPending[2] = {false, false};
+  // reference-compatible entry (bioem_hip_compare): the caller hands over a few conv spectra per call (ONE per call
+  // in the reference's default ALGO-1 loop, bioem.cpp:534,811-853).  They are staged into a two-half ring -- pinned
+  // host rows, H2D copies on their own stream -- and compared with ONE kernel launch per filled half (flush at
+  // finish_run), folding in call order through a per-row (orientation, CTF) table.  Half k uses buffer set k of
+  // the native pipeline (conv, params, cmpDone[k]).
+  struct CompatHalf
+  {
+    float2 *hConv = nullptr;          // pinned [ringCap][M], reference layout
+    bioem_hip_param5 *hPar = nullptr; // pinned [ringCap]
+    int2 *hIds = nullptr;             // pinned [ringCap] {orientation, CTF}
+    int4 *hSeg = nullptr;             // pinned [ringCap] runs of equal orientation {first row, end row, orientation, 0}
+    float2 *dStage = nullptr;         // device [ringCap][M], reference layout
+    int2 *dIds = nullptr;
+    int4 *dSeg = nullptr;
+    hipEvent_t staged = nullptr;      // H2D copies of this half done (copyStream)
+  };
+  CompatHalf ring[2];
+  int ringCap = 0, ringHalf = 0, ringCount = 0;
+  std::vector<int> ringOrients; // orientations with rows in the current half, in first-appearance order
+  hipStream_t copyStream = nullptr;
 
   // timing
   std::vector<hipEvent_t> evPool;
@@ -348,7 +361,10 @@ fast_kernel_t fast_kernel(int winD, int R, bool nyq, int gs)
                       : fast_kernel_g<15>(R, nyq, gs);
 }
 
-int launch_compare_fold(bioem_hip_ctx *h, const BatchBuf &bb, int nOC, int orient0, int conv0, int convPerOrient)
+// ids == nullptr: row oc of the launch is (orient0 + oc / convPerOrient, conv0 + oc % convPerOrient) (native path);
+// otherwise ids[oc] = {orientation, CTF} and segs[0..nSeg) = runs of equal orientation (compat ring)
+int launch_compare_fold(bioem_hip_ctx *h, const BatchBuf &bb, int nOC, int orient0, int conv0, int convPerOrient,
+                        const int2 *ids = nullptr, const int4 *segs = nullptr, int nSeg = 0)
 {
   CompareArgs a;
   a.ref = h->dRef;
@@ -381,6 +397,10 @@ int launch_compare_fold(bioem_hip_ctx *h, const BatchBuf &bb, int nOC, int orien
   hipEvent_t e0 = get_event(h), e1 = get_event(h);
   if (!e0 || !e1)
   {
+    if (e0)
+      h->evPool.push_back(e0);
+    if (e1)
+      h->evPool.push_back(e1);
     h->err = "hipEventCreate failed";
     return 1;
   }
@@ -495,23 +515,39 @@ int launch_compare_fold(bioem_hip_ctx *h, const BatchBuf &bb, int nOC, int orien
   static const bool serialFold = getenv("BIOEM_SERIAL_FOLD") != nullptr; // debugging: the one-thread-per-particle fold
   if (serialFold)
     hipLaunchKernelGGL(k_fold, dim3((h->nMaps + 127) / 128), dim3(128), 0, h->stream, h->dPartials, h->maxOC, nOC,
-                       h->nMaps, bb.params, h->dSumRef, h->dDisp, h->nd, h->pd, orient0, conv0, convPerOrient, pmap,
-                       pang);
+                       h->nMaps, bb.params, h->dSumRef, h->dDisp, h->nd, h->pd, orient0, conv0, convPerOrient, ids,
+                       pmap, pang);
   else
   {
     if (h->pd.writeAngles)
     {
-      const long long nt = (long long) ((nOC + convPerOrient - 1) / convPerOrient) * h->nMaps;
+      const int nRuns = ids ? nSeg : (nOC + convPerOrient - 1) / convPerOrient;
+      const long long nt = (long long) nRuns * h->nMaps;
       hipLaunchKernelGGL(k_fold_angles, dim3((unsigned) ((nt + 255) / 256)), dim3(256), 0, h->stream, h->dPartials,
-                         h->maxOC, nOC, h->nMaps, orient0, convPerOrient, pang);
+                         h->maxOC, nOC, h->nMaps, orient0, convPerOrient, segs, nRuns, pang);
     }
     hipLaunchKernelGGL(k_fold_wave, dim3((h->nMaps + 3) / 4), dim3(256), 0, h->stream, h->dPartials, h->maxOC, nOC,
-                       h->nMaps, bb.params, h->dSumRef, h->dDisp, h->nd, h->pd, orient0, conv0, convPerOrient, pmap);
+                       h->nMaps, bb.params, h->dSumRef, h->dDisp, h->nd, h->pd, orient0, conv0, convPerOrient, ids,
+                       pmap);
   }
   HIP_CHECK(h, hipGetLastError());
   if (h->evPending.size() > 512)
     drain_events(h);
   return 0;
+}
+
+// the exact-DFT r2c kernels keep one image row / column (and its twiddles) in dynamic LDS: 24 N + 16 and 32 N bytes.
+// Above 64 KiB a launch needs the explicit opt-in; 32 N <= 160 KiB bounds the image size at 5120 pixels (the
+// reference's MRC reader stops at 5000, mrc.h:128-133).
+const int kMaxPixels = 5120;
+hipError_t dft_allow_lds(int N)
+{
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_dft_rows), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     (int) (sizeof(double) * (3 * (size_t) N + 2)));
+  if (e != hipSuccess)
+    return e;
+  return hipFuncSetAttribute(reinterpret_cast<const void *>(k_dft_cols), hipFuncAttributeMaxDynamicSharedMemorySize,
+                             (int) (sizeof(double2) * 2 * (size_t) N));
 }
 
 void dft_split(int N, int &A, int &B)
@@ -547,6 +583,100 @@ int project_batch(bioem_hip_ctx *h, const BatchBuf &bb, hipStream_t st, int o0, 
                      h->isQuat, N, h->pixelSize, h->shiftX, h->shiftY, bb.projReal, bb.tempDen);
   HIP_CHECK(h, hipGetLastError());
   return run_r2c(h, bb, st, bb.projReal, nullptr, nO);
+}
+
+// ---- compat ring (bioem_hip_compare) ----
+int compat_alloc(bioem_hip_ctx *h)
+{
+  if (h->ringCap)
+    return 0;
+  int cap = 128; // rows per half: 128 x 1 000 particles = 2.6 ms of comparison kernel at 224^2
+  if (getenv("BIOEM_COMPAT_RING"))
+    cap = atoi(getenv("BIOEM_COMPAT_RING"));
+  cap = std::max(1, std::min(cap, h->maxOC));
+  const size_t M = (size_t) h->M;
+  for (int k = 0; k < 2; k++)
+  {
+    bioem_hip_ctx::CompatHalf &r = h->ring[k];
+    HIP_CHECK(h, hipHostMalloc(&r.hConv, sizeof(float2) * M * cap, hipHostMallocDefault));
+    HIP_CHECK(h, hipHostMalloc(&r.hPar, sizeof(bioem_hip_param5) * cap, hipHostMallocDefault));
+    HIP_CHECK(h, hipHostMalloc(&r.hIds, sizeof(int2) * cap, hipHostMallocDefault));
+    HIP_CHECK(h, hipHostMalloc(&r.hSeg, sizeof(int4) * cap, hipHostMallocDefault));
+    HIP_CHECK(h, hipMalloc(&r.dStage, sizeof(float2) * M * cap));
+    HIP_CHECK(h, hipMalloc(&r.dIds, sizeof(int2) * cap));
+    HIP_CHECK(h, hipMalloc(&r.dSeg, sizeof(int4) * cap));
+    HIP_CHECK(h, hipEventCreateWithFlags(&r.staged, hipEventDisableTiming));
+  }
+  HIP_CHECK(h, hipStreamCreateWithFlags(&h->copyStream, hipStreamNonBlocking));
+  h->ringCap = cap;
+  h->ringHalf = 0;
+  h->ringCount = 0;
+  return 0;
+}
+
+void compat_free(bioem_hip_ctx *h)
+{
+  for (int k = 0; k < 2; k++)
+  {
+    bioem_hip_ctx::CompatHalf &r = h->ring[k];
+    if (r.hConv)
+      hipHostFree(r.hConv);
+    if (r.hPar)
+      hipHostFree(r.hPar);
+    if (r.hIds)
+      hipHostFree(r.hIds);
+    if (r.hSeg)
+      hipHostFree(r.hSeg);
+    if (r.dStage)
+      hipFree(r.dStage);
+    if (r.dIds)
+      hipFree(r.dIds);
+    if (r.dSeg)
+      hipFree(r.dSeg);
+    if (r.staged)
+      hipEventDestroy(r.staged);
+    r = bioem_hip_ctx::CompatHalf();
+  }
+  if (h->copyStream)
+    hipStreamDestroy(h->copyStream);
+  h->copyStream = nullptr;
+  h->ringCap = h->ringCount = 0;
+}
+
+// launch the comparison of the rows staged in the current half, then switch halves
+int compat_flush(bioem_hip_ctx *h)
+{
+  const int n = h->ringCount;
+  if (n == 0)
+    return 0;
+  const int half = h->ringHalf;
+  bioem_hip_ctx::CompatHalf &r = h->ring[half];
+  const BatchBuf bb = batch_buf(h, half);
+  // runs of equal orientation (rows arrive in call order; an orientation never returns within a half, see compare)
+  int nSeg = 0;
+  for (int i = 0; i < n; i++)
+  {
+    if (nSeg && r.hSeg[nSeg - 1].z == r.hIds[i].x)
+      r.hSeg[nSeg - 1].y = i + 1;
+    else
+      r.hSeg[nSeg++] = make_int4(i, i + 1, r.hIds[i].x, 0);
+  }
+  HIP_CHECK(h, hipEventRecord(r.staged, h->copyStream));
+  HIP_CHECK(h, hipStreamWaitEvent(h->stream, r.staged, 0));
+  HIP_CHECK(h, hipMemcpyAsync(bb.params, r.hPar, sizeof(bioem_hip_param5) * n, hipMemcpyHostToDevice, h->stream));
+  HIP_CHECK(h, hipMemcpyAsync(r.dIds, r.hIds, sizeof(int2) * n, hipMemcpyHostToDevice, h->stream));
+  HIP_CHECK(h, hipMemcpyAsync(r.dSeg, r.hSeg, sizeof(int4) * nSeg, hipMemcpyHostToDevice, h->stream));
+  hipLaunchKernelGGL(k_reorder, dim3(std::min(2048, 8 * n)), dim3(256), 0, h->stream, r.dStage, bb.conv, n, h->N, h->H,
+                     h->fast, h->N1);
+  HIP_CHECK(h, hipGetLastError());
+  if (launch_compare_fold(h, bb, n, 0, 0, 1, r.dIds, r.dSeg, nSeg))
+    return 1;
+  HIP_CHECK(h, hipEventRecord(h->cmpDone[half], h->stream));
+  h->cmpPending[half] = true;
+  h->ringHalf ^= 1;
+  h->ringCount = 0;
+  h->ringOrients.clear();
+  return 0;
 }
 
 int convolve_batch(bioem_hip_ctx *h, const BatchBuf &bb, hipStream_t st, int nO)
@@ -605,7 +735,13 @@ int bioem_hip_create(bioem_hip_handle *out, int device, const bioem_hip_param_de
     h->err = "invalid configuration (need N>=2, nMaps,nAngles,nCTF>=1, 0<=maxD<N/2, grid>=1)";
     return 2;
   }
+  if (N > kMaxPixels)
+  {
+    h->err = "invalid configuration: images larger than 5120 x 5120 pixels are not supported";
+    return 2;
+  }
   HIP_CHECK(h, hipSetDevice(device));
+  HIP_CHECK(h, dft_allow_lds(N));
   {
     int prLow = 0, prHigh = 0;
     HIP_CHECK(h, hipDeviceGetStreamPriorityRange(&prLow, &prHigh));
@@ -907,8 +1043,6 @@ int bioem_hip_create(bioem_hip_handle *out, int device, const bioem_hip_param_de
       HIP_CHECK(h, hipMemcpy(h->dTwNyq, twn.data(), sizeof(float2) * twn.size(), hipMemcpyHostToDevice));
     }
   }
-  HIP_CHECK(h, hipEventCreateWithFlags(&h->slotEvent[0], hipEventDisableTiming));
-  HIP_CHECK(h, hipEventCreateWithFlags(&h->slotEvent[1], hipEventDisableTiming));
   return 0;
 }
 
@@ -924,20 +1058,15 @@ int bioem_hip_destroy(bioem_hip_handle h)
     hipEventDestroy(e);
   void *ptrs[] = {h->dRef,     h->dSumRef,  h->dSumsqRef, h->dCTF,     h->dCtfParam, h->dPts,   h->dAngles,
                   h->dTw,      h->dTwD,     h->dDisp,     h->dLtab,    h->dTwk,     h->dProjReal, h->dTempDen,  h->dRowSpec, h->dSpecRef,
-                  h->dScratch, h->dConv,    h->dParams,   h->dPartials, h->dProb,     h->dStage,
+                  h->dScratch, h->dConv,    h->dParams,   h->dPartials, h->dProb,
                   h->dProjReal2, h->dTempDen2, h->dRowSpec2, h->dSpecRef2, h->dScratch2, h->dConv2, h->dParams2,
                   h->dTnyq, h->dTwNyq, h->dPartTiles, h->dConvShift, h->dDispLocal, h->dRankOfRow, h->dTileCenter, h->dTileValid};
   for (void *p : ptrs)
     if (p)
       hipFree(p);
-  if (h->hStage)
-    hipHostFree(h->hStage);
-  if (h->hStageP)
-    hipHostFree(h->hStageP);
+  compat_free(h);
   for (int i = 0; i < 2; i++)
   {
-    if (h->slotEvent[i])
-      hipEventDestroy(h->slotEvent[i]);
     if (h->prepDone[i])
       hipEventDestroy(h->prepDone[i]);
     if (h->cmpDone[i])
@@ -1067,45 +1196,52 @@ int bioem_hip_compare(bioem_hip_handle h, int iPipeline, int iOrient, int iConvS
 {
   HIP_CHECK(h, hipSetDevice(h->device));
   const size_t M = (size_t) h->M;
-  if (maxParallelConv < 1 || maxParallelConv > nTotParallelConv || maxParallelConv > h->maxOC)
+  if (maxParallelConv < 1 || maxParallelConv > nTotParallelConv || iOrient < 0 || iOrient >= h->nAngles ||
+      iConvStart < 0 || iConvStart + maxParallelConv > h->nCTF)
   {
-    h->err = "bioem_hip_compare: maxParallelConv out of range";
+    h->err = "bioem_hip_compare: orientation / convolution range out of bounds";
     return 2;
   }
-  if (h->stageConv < nTotParallelConv)
-  {
-    HIP_CHECK(h, hipStreamSynchronize(h->stream));
-    if (h->hStage)
-      hipHostFree(h->hStage);
-    if (h->hStageP)
-      hipHostFree(h->hStageP);
-    if (h->dStage)
-      hipFree(h->dStage);
-    HIP_CHECK(h, hipHostMalloc(&h->hStage, sizeof(float2) * M * 2 * nTotParallelConv, hipHostMallocDefault));
-    HIP_CHECK(h, hipHostMalloc(&h->hStageP, sizeof(bioem_hip_param5) * 2 * nTotParallelConv, hipHostMallocDefault));
-    HIP_CHECK(h, hipMalloc(&h->dStage, sizeof(float2) * M * nTotParallelConv));
-    h->stageConv = nTotParallelConv;
-  }
-  const int par = iPipeline & 1;
-  const int k = par * nTotParallelConv; // bioem.cpp:1388
-  if (h->slotPending[par])
-  {
-    HIP_CHECK(h, hipEventSynchronize(h->slotEvent[par])); // bioem_cuda.cu:539
-    h->slotPending[par] = false;
-  }
-  memcpy(h->hStage + M * k, conv_mapsFFT + 2 * M * k, sizeof(float2) * M * maxParallelConv);
-  memcpy(h->hStageP + k, comp_params + k, sizeof(bioem_hip_param5) * maxParallelConv);
-  HIP_CHECK(h, hipMemcpyAsync(h->dStage, h->hStage + M * k, sizeof(float2) * M * maxParallelConv,
-                              hipMemcpyHostToDevice, h->stream));
-  HIP_CHECK(h, hipMemcpyAsync(h->dParams, h->hStageP + k, sizeof(bioem_hip_param5) * maxParallelConv,
-                              hipMemcpyHostToDevice, h->stream));
-  hipLaunchKernelGGL(k_reorder, dim3(256), dim3(256), 0, h->stream, h->dStage, h->dConv, maxParallelConv, h->N, h->H,
-                     h->fast, h->N1);
-  HIP_CHECK(h, hipGetLastError());
-  if (launch_compare_fold(h, batch_buf(h, 0), maxParallelConv, iOrient, iConvStart, maxParallelConv))
+  if (compat_alloc(h))
     return 1;
-  HIP_CHECK(h, hipEventRecord(h->slotEvent[par], h->stream));
-  h->slotPending[par] = true;
+  const int k = (iPipeline & 1) * nTotParallelConv; // bioem.cpp:1388
+  // with WRITE_PROB_ANGLES every orientation of a launch must be one run of rows: an orientation that returns after
+  // another one was staged starts a new launch
+  bool seen = false, last = !h->ringOrients.empty() && h->ringOrients.back() == iOrient;
+  for (int o : h->ringOrients)
+    seen = seen || o == iOrient;
+  if (seen && !last && compat_flush(h))
+    return 1;
+  int done = 0;
+  while (done < maxParallelConv)
+  {
+    if (h->ringCount == h->ringCap && compat_flush(h))
+      return 1;
+    const int half = h->ringHalf;
+    bioem_hip_ctx::CompatHalf &r = h->ring[half];
+    if (h->ringCount == 0 && h->cmpPending[half])
+    { // the launch that last used this half (two flushes ago) must have consumed its staged rows
+      HIP_CHECK(h, hipEventSynchronize(h->cmpDone[half]));
+      h->cmpPending[half] = false;
+    }
+    const int row0 = h->ringCount;
+    const int n = std::min(maxParallelConv - done, h->ringCap - row0);
+    // the caller's slot is free again when this returns (bioem_cuda.cu:539-561 makes the caller wait instead)
+    memcpy(r.hConv + M * row0, conv_mapsFFT + 2 * M * (size_t) (k + done), sizeof(float2) * M * n);
+    for (int i = 0; i < n; i++)
+    {
+      r.hPar[row0 + i] = comp_params[k + done + i];
+      r.hIds[row0 + i] = make_int2(iOrient, iConvStart + done + i);
+    }
+    HIP_CHECK(h, hipMemcpyAsync(r.dStage + M * row0, r.hConv + M * row0, sizeof(float2) * M * n, hipMemcpyHostToDevice,
+                                h->copyStream));
+    if (h->ringOrients.empty() || h->ringOrients.back() != iOrient)
+      h->ringOrients.push_back(iOrient);
+    h->ringCount += n;
+    done += n;
+  }
+  if (h->ringCount == h->ringCap && compat_flush(h))
+    return 1;
   return 0;
 }
 
@@ -1117,6 +1253,8 @@ int bioem_hip_project_convolve_compare(bioem_hip_handle h, int iOrientBegin, int
     h->err = "project_convolve_compare: model/orientations not uploaded or range invalid";
     return 2;
   }
+  if (compat_flush(h)) // rows staged through the reference-compatible entry go first (call order)
+    return 1;
   // two-slot pipeline: projection + convolution of batch b+1 run on prepStream while batch b is compared
   const int nb = (iOrientEnd - iOrientBegin + h->OB - 1) / h->OB;
   auto prep = [&](int b) -> int {
@@ -1162,9 +1300,10 @@ int bioem_hip_project_convolve_compare(bioem_hip_handle h, int iOrientBegin, int
 int bioem_hip_finish_run(bioem_hip_handle h, void *pProb_host)
 {
   HIP_CHECK(h, hipSetDevice(h->device));
+  if (compat_flush(h))
+    return 1;
   HIP_CHECK(h, hipMemcpyAsync(pProb_host, h->dProb, h->probBytes, hipMemcpyDeviceToHost, h->stream));
   HIP_CHECK(h, hipStreamSynchronize(h->stream));
-  h->slotPending[0] = h->slotPending[1] = false;
   drain_events(h);
   return 0;
 }
@@ -1172,6 +1311,8 @@ int bioem_hip_finish_run(bioem_hip_handle h, void *pProb_host)
 int bioem_hip_synchronize(bioem_hip_handle h)
 {
   HIP_CHECK(h, hipSetDevice(h->device));
+  if (compat_flush(h))
+    return 1;
   HIP_CHECK(h, hipStreamSynchronize(h->stream));
   return 0;
 }
@@ -1286,6 +1427,8 @@ int bioem_hip_debug_particles(bioem_hip_handle h, float *refFFT_out, float *sum_
 int bioem_hip_kernel_stats(bioem_hip_handle h, double *compare_ms, long long *launches, long long *comparisons)
 {
   HIP_CHECK(h, hipSetDevice(h->device));
+  if (compat_flush(h))
+    return 1;
   HIP_CHECK(h, hipStreamSynchronize(h->stream));
   drain_events(h);
   if (compare_ms)
@@ -1321,7 +1464,7 @@ const char *bioem_hip_kernel_name(bioem_hip_handle h)
 
 int bioem_hip_r2c(int device, int N, int nImg, const float *in, float *out)
 {
-  if (N < 1 || nImg < 1 || hipSetDevice(device) != hipSuccess)
+  if (N < 1 || N > kMaxPixels || nImg < 1 || hipSetDevice(device) != hipSuccess || dft_allow_lds(N) != hipSuccess)
     return 1;
   const int H = N / 2 + 1;
   const size_t M = (size_t) N * H;

@@ -13,7 +13,8 @@ namespace
 __global__ void k_fold(const Partial *__restrict__ partials, int ldPart, int nOC, int nMaps,
                        const bioem_hip_param5 *__restrict__ params, const float *__restrict__ sumRef,
                        const int *__restrict__ disp, int nd, PD pd, int orient0, int conv0, int convPerOrient,
-                       bioem_hip_prob_map *__restrict__ pmap, bioem_hip_prob_angle *__restrict__ pang)
+                       const int2 *__restrict__ ids, bioem_hip_prob_map *__restrict__ pmap,
+                       bioem_hip_prob_angle *__restrict__ pang)
 {
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= nMaps)
@@ -24,8 +25,8 @@ __global__ void k_fold(const Partial *__restrict__ partials, int ldPart, int nOC
   for (int oc = 0; oc < nOC; oc++)
   {
     const Partial r = P[oc];
-    const int iOrient = orient0 + oc / convPerOrient;
-    const int iConv = conv0 + oc % convPerOrient;
+    const int iOrient = ids ? ids[oc].x : orient0 + oc / convPerOrient;
+    const int iConv = ids ? ids[oc].y : conv0 + oc % convPerOrient;
     const double lp = (double) r.best;
     if (pm.Constoadd < lp)
     {
@@ -61,19 +62,28 @@ __global__ void k_fold(const Partial *__restrict__ partials, int ldPart, int nOC
 // WRITE_PROB_ANGLES table: one thread per (particle, orientation of this launch) folds that orientation's CTF
 // partials into its angle entry, in CTF order -- the same arithmetic sequence per entry as k_fold
 // (bioem_algorithm.h:130-141), but nMaps * nOrient threads instead of nMaps.  The particle entries are then
-// folded by k_fold_wave.
+// folded by k_fold_wave.  Rows of orientation j: [j*convPerOrient, (j+1)*convPerOrient) (native path, segs == null)
+// or the run segs[j] = {first row, end row, orientation} (compat ring: every orientation of a launch is ONE run).
 // ------------------------------------------------------------------------------------------------
 __global__ void k_fold_angles(const Partial *__restrict__ partials, int ldPart, int nOC, int nMaps, int orient0,
-                              int convPerOrient, bioem_hip_prob_angle *__restrict__ pang)
+                              int convPerOrient, const int4 *__restrict__ segs, int nRuns,
+                              bioem_hip_prob_angle *__restrict__ pang)
 {
-  const int nOrient = (nOC + convPerOrient - 1) / convPerOrient;
   const long long t = (long long) blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= (long long) nOrient * nMaps)
+  if (t >= (long long) nRuns * nMaps)
     return;
   const int j = (int) (t / nMaps), p = (int) (t - (long long) j * nMaps); // particle index fastest: coalesced table
   const Partial *P = partials + (size_t) p * ldPart;
-  bioem_hip_prob_angle pa = pang[(size_t) (orient0 + j) * nMaps + p];
-  for (int oc = j * convPerOrient; oc < min(nOC, (j + 1) * convPerOrient); oc++)
+  int ocBegin = j * convPerOrient, ocEnd = min(nOC, (j + 1) * convPerOrient), iOrient = orient0 + j;
+  if (segs)
+  {
+    const int4 sg = segs[j];
+    ocBegin = sg.x;
+    ocEnd = sg.y;
+    iOrient = sg.z;
+  }
+  bioem_hip_prob_angle pa = pang[(size_t) iOrient * nMaps + p];
+  for (int oc = ocBegin; oc < ocEnd; oc++)
   {
     const Partial r = P[oc];
     const double lp = (double) r.best;
@@ -84,7 +94,7 @@ __global__ void k_fold_angles(const Partial *__restrict__ partials, int ldPart, 
     }
     pa.forAngles += r.sumExp * exp(lp - pa.ConstAngle);
   }
-  pang[(size_t) (orient0 + j) * nMaps + p] = pa;
+  pang[(size_t) iOrient * nMaps + p] = pa;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -97,6 +107,7 @@ __global__ __launch_bounds__(256) void k_fold_wave(const Partial *__restrict__ p
                                                    int nMaps, const bioem_hip_param5 *__restrict__ params,
                                                    const float *__restrict__ sumRef, const int *__restrict__ disp,
                                                    int nd, PD pd, int orient0, int conv0, int convPerOrient,
+                                                   const int2 *__restrict__ ids,
                                                    bioem_hip_prob_map *__restrict__ pmap)
 {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -145,8 +156,8 @@ __global__ __launch_bounds__(256) void k_fold_wave(const Partial *__restrict__ p
       const int ix = r.id / nd, iy = r.id - ix * nd;
       pm.max_prob_cent_x = -disp[ix];
       pm.max_prob_cent_y = -disp[iy];
-      pm.max_prob_orient = orient0 + idx / convPerOrient;
-      pm.max_prob_conv = conv0 + idx % convPerOrient;
+      pm.max_prob_orient = ids ? ids[idx].x : orient0 + idx / convPerOrient;
+      pm.max_prob_conv = ids ? ids[idx].y : conv0 + idx % convPerOrient;
       const bioem_hip_param5 q = params[idx];
       const float sumref = sumRef[p];
       const float value = r.value;

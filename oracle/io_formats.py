@@ -8,6 +8,9 @@ Formats restated from the reference readers (not copied):
   * parameter file ........ /root/reference/param.cpp:121-527 (keyword per line, space separated)
   * text model ............ /root/reference/model.cpp:419-601 ("%lf %lf %lf %lf %lf", no blank lines)
   * text particles ........ /root/reference/map.cpp:268-414 ("PARTICLE" header, 33-byte records %8d%8d%16.8f)
+  * PDB model ............. /root/reference/model.cpp:85-329 (ATOM records with atom name CA; columns 18-20 residue,
+                            31-54 x y z; radius / electrons per residue type model.cpp:738-844)
+  * MRC density model ..... /root/reference/model.cpp:332-416 (mode-2 volume; one point per voxel, radius 2 px)
   * orientation list ...... /root/reference/param.cpp:1213-1327 (count line, then 12-char columns)
   * Output_Probabilities .. /root/reference/bioem.cpp:1077-1222
   * ANG_PROB .............. /root/reference/bioem.cpp:1050-1075,1245-1365
@@ -31,6 +34,60 @@ def write_text_model(path, pts):
     with open(path, "w") as f:
         lines = ["%.6f %.6f %.6f %.6f %.6f" % tuple(float(v) for v in p) for p in pts]
         f.write("\n".join(lines) + "\n")
+
+
+# residue -> (radius [A], electrons), restating /root/reference/model.cpp:738-844
+RESIDUES = {"CYS": (2.75, 64.0), "PHE": (3.2, 88.0), "LEU": (3.1, 72.0), "TRP": (3.4, 108.0), "VAL": (2.95, 64.0),
+            "ILE": (3.1, 72.0), "MET": (3.1, 80.0), "HIS": (3.05, 82.0), "TYR": (3.25, 96.0), "ALA": (2.5, 48.0),
+            "GLY": (2.25, 40.0), "PRO": (2.8, 62.0), "ASN": (2.85, 66.0), "THR": (2.8, 64.0), "SER": (2.6, 56.0),
+            "ARG": (3.3, 93.0), "GLN": (3.0, 78.0), "ASP": (2.8, 59.0), "LYS": (3.2, 79.0), "GLU": (2.95, 53.0)}
+
+
+def write_pdb_model(path, pts, resnames):
+    """C-alpha trace as fixed-column PDB records (80 columns, so that the reference's column reads never leave a
+    line), interleaved with records its reader must skip: backbone N/C atoms, HETATM, TER, REMARK, END."""
+    def rec(kind, serial, atom, res, seq, x, y, z, elem):
+        ln = "%-6s%5d  %-3s %3s A%4d    %8.3f%8.3f%8.3f  1.00  0.00          %2s" % (kind, serial, atom, res, seq, x, y,
+                                                                                   z, elem)
+        return ln.ljust(80) + "\n"
+    with open(path, "w") as f:
+        f.write("REMARK   1 GENERATED TEST MODEL (C-ALPHA TRACE)".ljust(80) + "\n")
+        serial = 1
+        for i, (p, res) in enumerate(zip(pts, resnames)):
+            f.write(rec("ATOM", serial, "N", res, i + 1, p[0] - 1.2, p[1] + 0.4, p[2], "N"))
+            f.write(rec("ATOM", serial + 1, "CA", res, i + 1, p[0], p[1], p[2], "C"))
+            f.write(rec("ATOM", serial + 2, "C", res, i + 1, p[0] + 1.1, p[1] - 0.7, p[2] + 0.5, "C"))
+            serial += 3
+        f.write("TER".ljust(80) + "\n")
+        f.write(rec("HETATM", serial, "CA", "CA", len(pts) + 1, 1.0, 2.0, 3.0, "CA"))
+        f.write("END".ljust(80) + "\n")
+
+
+def mrc_volume_points(vol, px):
+    """Points the reference's MRC model reader builds from a volume vol[i][j][k] stored in file order (first index
+    slowest): position ((i+1) - n/2) * px per axis, radius 2 px, density = voxel value (model.cpp:380-399)."""
+    nx, ny, nz = vol.shape
+    out = []
+    for i in range(1, nx + 1):
+        for j in range(1, ny + 1):
+            for k in range(1, nz + 1):
+                out.append([(i - nx / 2.0) * px, (j - ny / 2.0) * px, (k - nz / 2.0) * px, 2.0 * px,
+                            float(vol[i - 1, j - 1, k - 1])])
+    return np.array(out, dtype=np.float64)
+
+
+def write_mrc_volume(path, vol):
+    """mode-2 little-endian MRC volume; header words 1-3 = (nx, ny, nz) in the order the reference's model reader
+    loops over them (first slowest), cell 100 A / 90 degrees."""
+    import struct
+    nx, ny, nz = vol.shape
+    hdr = np.zeros(256, dtype="<i4")
+    hdr[0:4] = [nx, ny, nz, 2]
+    hdr[7:10] = [nx, ny, nz]
+    raw = hdr.tobytes()
+    raw = raw[:40] + struct.pack("<6f", 100., 100., 100., 90., 90., 90.) + raw[64:]
+    with open(path, "wb") as f:
+        f.write(raw + np.ascontiguousarray(vol, dtype="<f4").tobytes())
 
 
 def read_text_model(path):

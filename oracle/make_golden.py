@@ -63,6 +63,21 @@ def synth_model(rng, n, extent, rmin, rmax):
     return np.round(m, 6)
 
 
+def synth_pdb_model(rng, n, extent):
+    """C-alpha trace: coordinates with the 3 decimals a PDB record holds, residue names drawn from all 20 types;
+    radius / electrons from the residue tables (io_formats.RESIDUES, restating model.cpp:738-844)."""
+    pts = rng.normal(0.0, extent / 2.5, size=(n, 3))
+    r = np.linalg.norm(pts, axis=1)
+    pts[r > extent] *= (extent / r[r > extent])[:, None] * 0.95
+    pts = np.round(pts, 3)
+    names = sorted(iof.RESIDUES)
+    resnames = [names[int(k)] for k in rng.integers(0, len(names), size=n)]
+    resnames[:len(names)] = names[:n]  # every residue type at least once
+    rad = np.array([iof.RESIDUES[x][0] for x in resnames])
+    den = np.array([iof.RESIDUES[x][1] for x in resnames])
+    return np.concatenate([pts, rad[:, None], den[:, None]], axis=1), resnames
+
+
 def synth_particles(rng, model, rots, N, px, nP, snr, maxshift):
     """Independent (non-reference) image synthesis: Gaussian-blob projection + noise, z-scored."""
     maps = np.zeros((nP, N, N), dtype=np.float64)
@@ -232,6 +247,22 @@ def case_table():
                                       ("SIGMA_PRIOR_DEFOCUS", [0.4]), ("PRIOR_DEFOCUS_CENTER", [2.8]),
                                       ("DISPLACE_CENTER", [40, 1])],
                                   algos=[1, 2], snr=0.05, maxshift=30, seed=123)
+    # G24: model from a PDB file (--ReadPDB): C-alpha records only, residue radius / electron tables
+    # (model.cpp:85-329, 738-844); the file also carries non-CA atoms, HETATM, TER and REMARK records to be skipped
+    C["g24_n32_pdb"] = dict(N=32, px=3.0, nP=3, npts=40, extent=25.0, rad=None, orient=("list", 12),
+                            kw=[("CTF_B_ENV", [50.0, 150.0, 2]), ("CTF_DEFOCUS", [1.0, 2.0, 2]),
+                                ("CTF_AMPLITUDE", [0.1, 0.1, 1]), ("DISPLACE_CENTER", [3, 1])],
+                            algos=[1, 2], snr=0.3, maxshift=2, seed=124, model_format="pdb")
+    # G25: model from an MRC density map (--ReadModelMRC): one point per voxel, radius 2 px (model.cpp:332-416)
+    C["g25_n32_modelmrc"] = dict(N=32, px=3.0, nP=3, npts=0, extent=0.0, rad=None, orient=("list", 10),
+                                 kw=[("CTF_B_ENV", [50.0, 150.0, 2]), ("CTF_DEFOCUS", [1.0, 2.0, 2]),
+                                     ("CTF_AMPLITUDE", [0.1, 0.1, 1]), ("DISPLACE_CENTER", [3, 1])],
+                                 algos=[1], snr=0.3, maxshift=2, seed=125, model_format="mrc", voxels=(5, 6, 4))
+    # G26: particles from several MRC stacks named in a list file (--ReadMRC --ReadMultipleMRC, map.cpp:81-265)
+    C["g26_n32_multimrc"] = dict(N=32, px=3.0, nP=5, npts=25, extent=25.0, rad=(3.2, 3.4), orient=("list", 10),
+                                 kw=[("CTF_B_ENV", [50.0, 150.0, 2]), ("CTF_DEFOCUS", [1.0, 2.0, 2]),
+                                     ("CTF_AMPLITUDE", [0.1, 0.1, 1]), ("DISPLACE_CENTER", [3, 1])],
+                                 algos=[1], snr=0.3, maxshift=2, seed=126, particles="multimrc", stacks=(2, 3))
     only = os.environ.get("BIOEM_GOLDEN_ONLY")  # e.g. "g16,g17": restrict every stage to cases with these prefixes
     if only:
         C = {k: v for k, v in C.items() if any(k.startswith(o + "_") for o in only.split(","))}
@@ -294,7 +325,14 @@ def prepare():
         d = os.path.join(CASES_DIR, name)
         os.makedirs(d, exist_ok=True)
         rng = np.random.default_rng(c["seed"])
-        model = synth_model(rng, c["npts"], c["extent"], *c["rad"])
+        mformat = c.get("model_format", "text")
+        if mformat == "pdb":
+            model, resnames = synth_pdb_model(rng, c["npts"], c["extent"])
+        elif mformat == "mrc":
+            vol = np.round(rng.uniform(0.1, 1.0, size=c["voxels"]), 6).astype(np.float32)
+            model = iof.mrc_volume_points(vol, c["px"])
+        else:
+            model = synth_model(rng, c["npts"], c["extent"], *c["rad"])
         rots = orientation_rots(c["orient"], qlines)
         maps = synth_particles(rng, model, rots, c["N"], c["px"], c["nP"], c["snr"], c["maxshift"])
         kw = [("PIXEL_SIZE", [c["px"]]), ("NUMBER_PIXELS", [c["N"]])]
@@ -302,9 +340,23 @@ def prepare():
             kw.append(("USE_QUATERNIONS", []))
         kw += c["kw"]
         iof.write_param_file(os.path.join(d, "param.txt"), kw)
-        iof.write_text_model(os.path.join(d, "model.txt"), model)
+        if mformat == "pdb":
+            iof.write_pdb_model(os.path.join(d, "model.pdb"), model, resnames)
+        elif mformat == "mrc":
+            iof.write_mrc_volume(os.path.join(d, "model.mrc"), vol)
+        else:
+            iof.write_text_model(os.path.join(d, "model.txt"), model)
         pformat = c.get("particles", "text")
-        if pformat == "mrc":
+        if pformat == "multimrc":
+            # several stacks + a list file with one path per line (written by the run stage: absolute paths)
+            raw = (2.5 * maps + 6.0).astype(np.float32)
+            lo = 0
+            for k, cnt in enumerate(c["stacks"]):
+                write_mrc_stack(os.path.join(d, "stack%d.mrc" % k), raw[lo:lo + cnt])
+                lo += cnt
+            assert lo == len(raw)
+            maps = raw
+        elif pformat == "mrc":
             # raw un-normalised counts in FILE order (section, row, column); the reader transposes and z-scores
             raw = (2.5 * maps + 6.0).astype(np.float32)
             write_mrc_stack(os.path.join(d, "particles.mrc"), raw)
@@ -331,7 +383,8 @@ def prepare():
         np.savez_compressed(os.path.join(d, "inputs.npz"), model=model, maps=maps,
                             orient_lines=np.array(orient_lines), N=c["N"], px=c["px"],
                             algos=np.array(c["algos"]), trace=bool(c.get("trace", False)),
-                            particles=pformat, env_keys=np.array(list(c.get("env", {}).keys())),
+                            particles=pformat, model_format=mformat,
+                            stacks=np.array(c.get("stacks", ()), dtype=np.int64), env_keys=np.array(list(c.get("env", {}).keys())),
                             env_vals=np.array(list(c.get("env", {}).values())))
         print("prepared", name, maps.shape)
 
@@ -339,6 +392,8 @@ def prepare():
 def run():
     binary = os.path.join(HERE, "_ref", "bioEM_ref")
     binary_trace = os.path.join(HERE, "_ref", "bioEM_ref_trace")
+    # the reference driving libbioem_hip.so through its own compareRefMaps virtual (oracle/ref_plugin, GPU=1)
+    binary_hip = os.path.join(HERE, "_ref", "bioEM_ref_hip")
     ok = True
     for name in sorted(case_table()):
         d = os.path.join(CASES_DIR, name)
@@ -346,27 +401,48 @@ def run():
         out = os.path.join(OUT_DIR, name)
         os.makedirs(out, exist_ok=True)
         for algo in [int(a) for a in inp["algos"]]:
-            for exe, tag in ([(binary, "")] + ([(binary_trace, "_trace")] if bool(inp["trace"]) else [])):
+            runs = [(binary, "_algo%d" % algo)] + ([(binary_trace, "_algo%d_trace" % algo)] if bool(inp["trace"]) else [])
+            if os.path.exists(binary_hip) and os.environ.get("BIOEM_GOLDEN_PLUGIN", "1") != "0":
+                runs.append((binary_hip, "_plugin_algo%d" % algo))
+            if os.environ.get("BIOEM_GOLDEN_PLUGIN_ONLY"):
+                runs = [r_ for r_ in runs if r_[0] == binary_hip]
+            for exe, tag in runs:
                 env = dict(os.environ, OMP_NUM_THREADS="1", BIOEM_ALGO=str(algo), BIOEM_DEBUG_OUTPUT="0")
                 env.pop("GPU", None)
+                if exe == binary_hip:
+                    env["GPU"] = "1"
+                    if algo == 2:  # several convolutions per compareRefMaps call (nTotParallelConv = min(nCTF, 3))
+                        env["BIOEM_PROJ_CONV_AT_ONCE"] = "3"
                 if "env_keys" in inp.files:
                     for k_, v_ in zip(inp["env_keys"], inp["env_vals"]):
                         env[str(k_)] = str(v_)
                 pformat = str(inp["particles"]) if "particles" in inp.files else "text"
-                pfile = "particles.mrc" if pformat == "mrc" else "particles.txt"
-                cmd = [exe, "--Modelfile", os.path.join(d, "model.txt"), "--Particlesfile",
+                mformat = str(inp["model_format"]) if "model_format" in inp.files else "text"
+                pfile = {"mrc": "particles.mrc", "multimrc": "list.txt"}.get(pformat, "particles.txt")
+                mfile = {"pdb": "model.pdb", "mrc": "model.mrc"}.get(mformat, "model.txt")
+                if pformat == "multimrc":
+                    with open(os.path.join(d, "list.txt"), "w") as f:
+                        for k_ in range(len(inp["stacks"])):
+                            f.write(os.path.join(d, "stack%d.mrc" % k_) + "\n")
+                cmd = [exe, "--Modelfile", os.path.join(d, mfile), "--Particlesfile",
                        os.path.join(d, pfile), "--Inputfile", os.path.join(d, "param.txt"),
-                       "--OutputFile", "Output_Probabilities_algo%d%s" % (algo, tag)]
-                if pformat == "mrc":
+                       "--OutputFile", "Output_Probabilities%s" % tag]
+                if pformat in ("mrc", "multimrc"):
                     cmd.append("--ReadMRC")
+                if pformat == "multimrc":
+                    cmd.append("--ReadMultipleMRC")
+                if mformat == "pdb":
+                    cmd.append("--ReadPDB")
+                if mformat == "mrc":
+                    cmd.append("--ReadModelMRC")
                 if os.path.exists(os.path.join(d, "orient.txt")):
                     cmd += ["--ReadOrientation", os.path.join(d, "orient.txt")]
                 r = subprocess.run(cmd, cwd=out, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
-                with open(os.path.join(out, "stdout_algo%d%s.txt" % (algo, tag)), "w") as f:
+                with open(os.path.join(out, "stdout%s.txt" % tag), "w") as f:
                     f.write(r.stdout)
                 if os.path.exists(os.path.join(out, "ANG_PROB")):
-                    os.replace(os.path.join(out, "ANG_PROB"), os.path.join(out, "ANG_PROB_algo%d%s" % (algo, tag)))
-                print(name, "algo", algo, tag, "rc", r.returncode, flush=True)
+                    os.replace(os.path.join(out, "ANG_PROB"), os.path.join(out, "ANG_PROB%s" % tag))
+                print(name, tag, "rc", r.returncode, flush=True)
                 ok = ok and r.returncode == 0
     sys.exit(0 if ok else 1)
 
@@ -380,8 +456,9 @@ def collect():
             continue
         dst = os.path.join(GOLD_DIR, name)
         os.makedirs(dst, exist_ok=True)
-        for f in ["inputs.npz", "param.txt"]:
-            shutil.copy(os.path.join(src_in, f), dst)
+        for f in ["inputs.npz", "param.txt", "model.pdb", "model.mrc"]:
+            if os.path.exists(os.path.join(src_in, f)):
+                shutil.copy(os.path.join(src_in, f), dst)
         for f in os.listdir(src_out):
             if f.startswith("Output_Probabilities") or f.startswith("ANG_PROB"):
                 shutil.copy(os.path.join(src_out, f), dst)

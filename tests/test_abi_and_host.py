@@ -212,3 +212,38 @@ def test_merge_host_equals_oracle_merge():
         # merged shards == unsharded run (associativity of the log-sum-exp fold)
         assert abs(S.final_logp(a) - S.final_logp(c)) < 1e-9 * abs(S.final_logp(c))
         assert (a["orient"], a["conv"], a["cent_x"], a["cent_y"]) == (c["orient"], c["conv"], c["cent_x"], c["cent_y"])
+
+
+# ------------------------------------------------------------------------------------------------------
+# readers against the fixtures the REFERENCE was run on (tests/golden/g24-g26: the model / particle files fed to
+# oracle/_ref/bioEM_ref with --ReadPDB, --ReadModelMRC, --ReadMRC --ReadMultipleMRC; its Output_Probabilities are
+# checked against the oracle on these points in test_oracle_golden.py and against the CLI in the GPU suite)
+# ------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name,kind", [("g24_n32_pdb", dict(isPDB=True)), ("g25_n32_modelmrc", dict(isMRC=True))])
+def test_model_readers_deliver_the_golden_points(name, kind):
+    from bioem_amd import hostlib
+    case = load_case(name)
+    mfile = os.path.join(case["dir"], "model.pdb" if "isPDB" in kind else "model.mrc")
+    pts, nd = hostlib.read_model(mfile, nocentermass=True, pixelSize=case["P"]["pixelSize"], **kind)
+    want = case["model"]
+    assert len(pts) == len(want)
+    assert np.array_equal(pts["pos"], want[:, :3].astype(np.float32))
+    assert np.array_equal(pts["radius"], want[:, 3].astype(np.float32))
+    assert np.array_equal(pts["density"], want[:, 4].astype(np.float32))
+    assert abs(float(nd) - want[:, 4].sum()) <= 1e-4 * want[:, 4].sum()
+
+
+def test_multiple_mrc_reader_delivers_the_golden_maps(tmp_path):
+    from bioem_amd import hostlib
+    from golden_util import write_case_inputs
+    case = load_case("g26_n32_multimrc")
+    assert case["particles"] == "multimrc" and len(case["stacks"]) == 2
+    write_case_inputs(case, tmp_path)
+    cwd = os.getcwd()
+    os.chdir(tmp_path)          # the list names its stacks relative to the run directory
+    try:
+        maps = hostlib.read_particles("list.txt", case["P"]["N"], mode=2)
+    finally:
+        os.chdir(cwd)
+    assert maps.shape == case["maps"].shape
+    assert np.allclose(maps, case["maps"], rtol=0, atol=2e-6)

@@ -14,7 +14,7 @@ import pytest
 
 import io_formats as iof
 import oracle as orc
-from golden_util import CASES, golden_output, load_case, oracle_setup
+from golden_util import CASES, golden_output, load_case, oracle_setup, write_case_inputs
 
 pytestmark = pytest.mark.gpu
 
@@ -233,21 +233,10 @@ def test_invalid_configuration_is_rejected():
     E.close()
 
 
-def _write_mrc_stack(path, data):
-    import struct
-    ns, nr, nc = data.shape
-    hdr = np.zeros(256, dtype="<i4")
-    hdr[0:4] = [nc, nr, ns, 2]
-    hdr[7:10] = [nc, nr, ns]
-    raw = hdr.tobytes()
-    raw = raw[:40] + struct.pack("<6f", 100., 100., 100., 90., 90., 90.) + raw[64:]
-    with open(path, "wb") as f:
-        f.write(raw + data.astype("<f4").tobytes())
-
-
 CLI_CASES = ["g10_n64", "g9_n35_odd", "g4_n32_angles", "g5_n32_psf", "g11_n32_eulerlist", "g12_n32_misc",
              "g13_n32_psf_writectf", "g14_n32_mrc", "g15_n32_mrc_nonorm", "g16_n40", "g17_n36", "g18_n50",
-             "g20_n256", "g21_n64_wide20", "g22_n128_wide40", "g23_n128_tutorial"]
+             "g20_n256", "g21_n64_wide20", "g22_n128_wide40", "g23_n128_tutorial", "g24_n32_pdb", "g25_n32_modelmrc",
+             "g26_n32_multimrc"]
 
 
 # (case, orientation shards): BIOEM_SHARDS > 1 runs the CLI's multi-GPU control flow (one engine context and host
@@ -258,26 +247,16 @@ CLI_RUNS = [(c, 1) for c in CLI_CASES] + [("g10_n64", 3), ("g4_n32_angles", 2), 
 
 @pytest.mark.parametrize("name,shards", CLI_RUNS)
 def test_cli_end_to_end_against_reference_outputs(name, shards, tmp_path):
-    """The drop-in CLI (--Modelfile/--Particlesfile/--Inputfile[/--ReadOrientation][/--ReadMRC]) on the golden
+    """The drop-in CLI (--Modelfile/--Particlesfile/--Inputfile[/--ReadOrientation][/--ReadMRC [--ReadMultipleMRC]]
+    [/--ReadPDB | --ReadModelMRC]) on the golden
     inputs, with the same files, options and environment the reference was run with: Output_Probabilities /
     ANG_PROB parsed and compared with the reference's own files; the header block must be byte-identical."""
     exe = os.path.join(ROOT, "bioem_amd", "bin", "bioEM")
     assert os.path.exists(exe), "CLI not built"
     case, S = setup_for(name)
     d = tmp_path
-    iof.write_text_model(str(d / "model.txt"), case["model"])
-    if case["particles"] == "mrc":
-        _write_mrc_stack(str(d / "particles.mrc"), case["raw_maps"])
-        pargs = ["--Particlesfile", "particles.mrc", "--ReadMRC"]
-    else:
-        iof.write_text_particles(str(d / "particles.txt"), case["maps"])
-        pargs = ["--Particlesfile", "particles.txt"]
-    cmd = [exe, "--Modelfile", "model.txt", "--Inputfile", os.path.join(case["dir"], "param.txt"), "--OutputFile",
-           "out.txt"] + pargs
-    if case["orient_lines"]:
-        with open(d / "orient.txt", "w") as f:
-            f.write("%d\n" % len(case["orient_lines"]) + "\n".join(case["orient_lines"]) + "\n")
-        cmd += ["--ReadOrientation", "orient.txt"]
+    cmd = [exe, "--Inputfile", os.path.join(case["dir"], "param.txt"), "--OutputFile", "out.txt"] + \
+        write_case_inputs(case, d)
     for algo in case["algos"]:
         env = dict(os.environ, BIOEM_ALGO=str(algo), BIOEM_GPUS="1", BIOEM_SHARDS=str(shards))
         env.update(case["env"])

@@ -126,3 +126,33 @@ def test_per_displacement_trace():
     # printed with %f (6 decimals); value differences are float rounding of the FFT backend
     assert worst_v <= 2e-6 * vscale + 1e-5
     assert worst_l <= 2e-3
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_reference_driving_the_hip_plugin_equals_reference_cpu(name):
+    """The compiled drop-in proof: oracle/_ref/bioEM_ref_hip = the UNMODIFIED reference sources built with -DWITH_CUDA
+    plus oracle/ref_plugin/bioem_hip_plugin.cpp (class bioem_hip : public bioem, bioem_cuda_create()), linked against
+    libbioem_hip.so.  Run with GPU=1 on the MI355X box by `oracle/make_golden.py run`, the reference's own run() loop
+    (host projection / convolution, bioem.cpp:763-891) called the engine through the compareRefMaps virtual
+    (bioem.cpp:853): one convolution per call for ALGO 1, up to three (BIOEM_PROJ_CONV_AT_ONCE=3) for ALGO 2.  Its
+    committed outputs must equal the reference CPU path's outputs on the same inputs."""
+    case = load_case(name)
+    for algo in case["algos"]:
+        ref = iof.parse_output_probabilities(golden_output(case, algo))
+        plug = iof.parse_output_probabilities(golden_output(case, algo, plugin=True))
+        assert len(ref) == len(plug) > 0
+        for a, b in zip(ref, plug):
+            assert abs(a["logp"] - b["logp"]) <= 1e-4 * abs(a["logp"]) and abs(a["logp"] - b["logp"]) <= ABS_TOL
+            assert (a["angles"], a["ctf"], a["cx"], a["cy"]) == (b["angles"], b["ctf"], b["cx"], b["cy"])
+            assert abs(a["norm"] - b["norm"]) <= 2e-4 and abs(a["mu"] - b["mu"]) <= 2e-4
+        # the header block (notation, units) is the reference's own writer either way
+        assert golden_output(case, algo).split("\n\n")[0] == golden_output(case, algo, plugin=True).split("\n\n")[0]
+        ang = os.path.join(case["dir"], "ANG_PROB_algo%d" % algo)
+        if os.path.exists(ang):
+            ga = iof.parse_ang_prob(ang)
+            pa = iof.parse_ang_prob(os.path.join(case["dir"], "ANG_PROB_plugin_algo%d" % algo))
+            assert sorted(ga) == sorted(pa)
+            for m in ga:
+                assert len(ga[m]) == len(pa[m])
+                for g, p in zip(ga[m], pa[m]):
+                    assert g["angles"] == p["angles"] and abs(g["logp"] - p["logp"]) <= ABS_TOL
