@@ -1240,7 +1240,15 @@ int bioem_hip_compare(bioem_hip_handle h, int iPipeline, int iOrient, int iConvS
     h->ringCount += n;
     done += n;
   }
-  if (h->ringCount == h->ringCap && compat_flush(h))
+  // launch when the half is full -- or earlier when the device has nothing left to do and a launch's worth of rows
+  // (32 x nMaps comparisons) is waiting: keeps the GPU busy while a short run ramps up
+  bool launch = h->ringCount == h->ringCap;
+  if (!launch && h->ringCount >= 32)
+  {
+    const int other = h->ringHalf ^ 1;
+    launch = !h->cmpPending[other] || hipEventQuery(h->cmpDone[other]) == hipSuccess;
+  }
+  if (launch && compat_flush(h))
     return 1;
   return 0;
 }

@@ -18,6 +18,9 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--pixels", type=int, default=224)
 ap.add_argument("--particles", type=int, default=1000)
 ap.add_argument("--orientations", type=int, default=64)
+ap.add_argument("--convs-per-call", type=int, default=0,
+                help="convolutions handed over per call (default: all CTFs of an orientation; 1 = the reference's "
+                     "default ALGO-1 loop, nTotParallelConv = 1, bioem.cpp:534)")
 args = ap.parse_args()
 
 W = Workload(N=args.pixels, nP=args.particles, nOrient=args.orientations)
@@ -30,18 +33,24 @@ for o in range(args.orientations):
         spec, sumC, sumsqC = E.debug_convolution(o, c)
         convs[o, c] = spec
         pars[o, c] = (W.ctfParam[c][0], W.ctfParam[c][1], W.ctfParam[c][2], sumC, sumsqC)
-conv_base = np.zeros((2 * nC, args.pixels, H, 2), dtype=np.float32)
-par_base = np.zeros(2 * nC, dtype=eng.PARAM5_DTYPE)
+nPar = args.convs_per_call if args.convs_per_call > 0 else nC
+conv_base = np.zeros((2 * nPar, args.pixels, H, 2), dtype=np.float32)
+par_base = np.zeros(2 * nPar, dtype=eng.PARAM5_DTYPE)
+ncalls = args.orientations * ((nC + nPar - 1) // nPar)
 
 
 def one_pass():
     raw, pmap, _ = eng.new_prob_block(W.nP, W.nOrient, 0)
     E.start_run(raw)
+    ipipe = 0
     for o in range(args.orientations):
-        k = (o & 1) * nC
-        conv_base[k:k + nC] = convs[o]          # the host's "createConvolutedProjectionMap" output lands here
-        par_base[k:k + nC] = pars[o]
-        E.compare(o, o, 0, nC, nC, conv_base, par_base)
+        for c0 in range(0, nC, nPar):
+            n = min(nPar, nC - c0)
+            k = (ipipe & 1) * nPar
+            conv_base[k:k + n] = convs[o, c0:c0 + n]   # the host's "createConvolutedProjectionMap" output lands here
+            par_base[k:k + n] = pars[o, c0:c0 + n]
+            E.compare(ipipe, o, c0, n, nPar, conv_base, par_base)
+            ipipe += 1
     E.finish_run(raw)
     return pmap
 
@@ -61,5 +70,5 @@ la = np.log(got["Total"]) + got["Constoadd"]
 lb = np.log(pmap["Total"]) + pmap["Constoadd"]
 n = args.orientations * nC * args.particles
 print("compat entry: %d comparisons in %.1f ms = %.2f M comparisons/s (%.2f MB handed over per call, %d calls); "
-      "max |dlogP| vs device path %.2e" % (n, dt * 1e3, n / dt / 1e6, nC * args.pixels * H * 8 / 1e6, args.orientations,
+      "max |dlogP| vs device path %.2e" % (n, dt * 1e3, n / dt / 1e6, nPar * args.pixels * H * 8 / 1e6, ncalls,
                                           np.abs(la - lb).max()))

@@ -122,6 +122,51 @@ def test_reference_compatible_compare_entry(name):
     E.close()
 
 
+@pytest.mark.parametrize("name,ring,order", [("g4_n32_angles", 4, "orient"), ("g4_n32_angles", 3, "ctf"),
+                                             ("g10_n64", 5, "orient"), ("g8_n32_grid", 1, "orient"),
+                                             ("g11_n32_eulerlist", 7, "ctf")])
+def test_compare_entry_ring_ragged_flushes(name, ring, order, monkeypatch):
+    """The reference-compatible entry stages rows into a ring and launches one comparison per filled half.  Small
+    rings (BIOEM_COMPAT_RING rows per half) make launches start in the middle of a call and in the middle of an
+    orientation's CTFs; order "ctf" walks the CTF blocks in the outer loop, so every orientation returns after other
+    ones were staged (the WRITE_PROB_ANGLES runs must then not be split inside one launch).  Folding in call order,
+    the particle entries AND the angle table must match the oracle fed with the same call sequence; one conv per
+    call = the reference's default ALGO-1 loop (nTotParallelConv = 1, bioem.cpp:534)."""
+    import bioem_amd.engine as eng
+    monkeypatch.setenv("BIOEM_COMPAT_RING", str(ring))
+    case, S = setup_for(name)
+    for algo in case["algos"]:
+        E = make_engine(S, algo)
+        nPar = 1 if ring == 1 else min(3, S.nCTF)
+        conv_base = np.zeros((2 * nPar, S.N, S.H, 2), dtype=np.float32)
+        par_base = np.zeros(2 * nPar, dtype=eng.PARAM5_DTYPE)
+        raw, pmap, pang = eng.new_prob_block(S.nMaps, S.nAngles, S.pd.writeAngles)
+        E.start_run(raw)
+        want, wang = S.new_prob()
+        calls = [(io, c0) for io in range(S.nAngles) for c0 in range(0, S.nCTF, nPar)]
+        if order == "ctf":
+            calls = [(io, c0) for c0 in range(0, S.nCTF, nPar) for io in range(S.nAngles)]
+        convs = {}
+        for ipipe, (io, c0) in enumerate(calls):
+            if io not in convs:
+                convs[io] = S.conv_spectra(io)
+            conv, p5 = convs[io]
+            n = min(nPar, S.nCTF - c0)
+            k = (ipipe & 1) * nPar
+            conv_base[k:k + n] = conv[c0:c0 + n]
+            par_base[k:k + n] = p5[c0:c0 + n]
+            E.compare(ipipe, io, c0, n, nPar, conv_base, par_base)
+            conv_base[k:k + n] = 7.0        # the slot is the caller's again as soon as the call returns
+            S.compare(algo, io, c0, conv[c0:c0 + n], p5[c0:c0 + n], want, wang)
+        E.finish_run(raw)
+        assert_same_posterior(S, pmap, want)
+        if S.pd.writeAngles:
+            la = np.log(pang["forAngles"]) + pang["ConstAngle"]
+            lb = np.log(wang["forAngles"]) + wang["ConstAngle"]
+            assert np.abs(la - lb).max() <= 5e-3
+        E.close()
+
+
 @pytest.mark.parametrize("name", ["g10_n64", "g9_n35_odd", "g6_n32_euler", "g7_n224"])
 def test_device_projection_and_convolution(name):
     """createProjection / createConvolutedProjectionMap on the device vs the oracle (spectra, sumC, sumsquareC)."""
