@@ -30,12 +30,18 @@
 // file is compiled with -ffp-contract=off (FMAs only where fmaf() is spelled out).  Sums that the reference
 // accumulates sequentially in float (sumsquareC, particle sums) are accumulated in the same order.
 #include <hip/hip_runtime.h>
+#include <rccl/rccl.h> // types only: the library itself is loaded on the first bioem_hip_merge (dlopen)
+
+#include <dlfcn.h>
 
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
+#include <mutex>
+#include <queue>
 #include <string>
 #include <vector>
 
@@ -136,7 +142,15 @@ struct bioem_hip_ctx
   bioem_hip_param5 *dParams = nullptr;
   Partial *dPartials = nullptr; // [nMaps][maxOC]
   unsigned char *dProb = nullptr;
-  size_t probBytes = 0;
+  size_t probBytes = 0;    // bytes start_run / finish_run move (shard handles: the map entries only)
+  size_t devProbBytes = 0; // device block: map entries + the angle table of the owned orientations
+  bool shard = false;      // created by bioem_hip_create_shard
+  int angO0 = 0, angO1 = 0; // orientations whose angle entries this handle holds ([0, nAngles) unless a shard)
+  bioem_hip_angle_candidate *dCand = nullptr; // [nMaps][candK] result of the last top-K selection
+  int candK = 0;
+  unsigned char *dSend = nullptr, *dRecv = nullptr; // RCCL merge buffers
+  size_t sendBytes = 0, recvBytes = 0;
+  bioem_hip_prob_map *dMerged = nullptr;
 
   // second buffer set + stream: projection/convolution of batch k+1 overlap the comparison of batch k
   hipStream_t prepStream = nullptr;
@@ -516,7 +530,7 @@ int launch_compare_fold(bioem_hip_ctx *h, const BatchBuf &bb, int nOC, int orien
   if (serialFold)
     hipLaunchKernelGGL(k_fold, dim3((h->nMaps + 127) / 128), dim3(128), 0, h->stream, h->dPartials, h->maxOC, nOC,
                        h->nMaps, bb.params, h->dSumRef, h->dDisp, h->nd, h->pd, orient0, conv0, convPerOrient, ids,
-                       pmap, pang);
+                       pmap, pang, h->angO0);
   else
   {
     if (h->pd.writeAngles)
@@ -524,7 +538,7 @@ int launch_compare_fold(bioem_hip_ctx *h, const BatchBuf &bb, int nOC, int orien
       const int nRuns = ids ? nSeg : (nOC + convPerOrient - 1) / convPerOrient;
       const long long nt = (long long) nRuns * h->nMaps;
       hipLaunchKernelGGL(k_fold_angles, dim3((unsigned) ((nt + 255) / 256)), dim3(256), 0, h->stream, h->dPartials,
-                         h->maxOC, nOC, h->nMaps, orient0, convPerOrient, segs, nRuns, pang);
+                         h->maxOC, nOC, h->nMaps, orient0, convPerOrient, segs, nRuns, pang, h->angO0);
     }
     hipLaunchKernelGGL(k_fold_wave, dim3((h->nMaps + 3) / 4), dim3(256), 0, h->stream, h->dPartials, h->maxOC, nOC,
                        h->nMaps, bb.params, h->dSumRef, h->dDisp, h->nd, h->pd, orient0, conv0, convPerOrient, ids,
@@ -679,10 +693,11 @@ int compat_flush(bioem_hip_ctx *h)
   return 0;
 }
 
-int convolve_batch(bioem_hip_ctx *h, const BatchBuf &bb, hipStream_t st, int nO)
+// conv spectra of CTFs [c0, c0 + nC) of the nO projected orientations, row ob * nC + (c - c0)
+int convolve_batch(bioem_hip_ctx *h, const BatchBuf &bb, hipStream_t st, int nO, int c0, int nC)
 {
-  hipLaunchKernelGGL(k_convolve, dim3(h->nCTF, nO), dim3(256), 0, st, bb.specRef, h->dCTF, h->dCtfParam, h->N, h->H,
-                     h->fast, h->N1, h->nCTF, bb.conv, bb.scratch, bb.params);
+  hipLaunchKernelGGL(k_convolve, dim3(nC, nO), dim3(256), 0, st, bb.specRef, h->dCTF, h->dCtfParam, h->N, h->H,
+                     h->fast, h->N1, c0, bb.conv, bb.scratch, bb.params);
   HIP_CHECK(h, hipGetLastError());
   return 0;
 }
@@ -712,13 +727,16 @@ size_t bioem_hip_prob_size(int nMaps, int nAngles, int writeAngles)
 
 const char *bioem_hip_last_error(bioem_hip_handle h) { return h ? h->err.c_str() : "null handle"; }
 
-int bioem_hip_create(bioem_hip_handle *out, int device, const bioem_hip_param_device *pd, int nMaps, int nAngles,
-                     int nCTF, int algo)
+static int create_impl(bioem_hip_handle *out, int device, const bioem_hip_param_device *pd, int nMaps, int nAngles,
+                       int nCTF, int algo, bool shard, int angO0, int angO1)
 {
   if (!out || !pd)
     return 2;
   bioem_hip_ctx *h = new bioem_hip_ctx;
   *out = h;
+  h->shard = shard;
+  h->angO0 = angO0;
+  h->angO1 = angO1;
   h->device = device;
   h->pd = *pd;
   h->nMaps = nMaps;
@@ -733,6 +751,11 @@ int bioem_hip_create(bioem_hip_handle *out, int device, const bioem_hip_param_de
       pd->maxDisplaceCenter >= N / 2)
   {
     h->err = "invalid configuration (need N>=2, nMaps,nAngles,nCTF>=1, 0<=maxD<N/2, grid>=1)";
+    return 2;
+  }
+  if (angO0 < 0 || angO1 > nAngles || angO0 >= angO1)
+  {
+    h->err = "invalid configuration: orientation range of the shard must be a non-empty part of [0, nAngles)";
     return 2;
   }
   if (N > kMaxPixels)
@@ -920,8 +943,8 @@ int bioem_hip_create(bioem_hip_handle *out, int device, const bioem_hip_param_de
     h->pchunk = atoi(getenv("BIOEM_PCHUNK"));
   if (getenv("BIOEM_BATCH_ORIENTATIONS")) // tuning knob: orientations per batch (conv buffer = OB*nCTF spectra)
     OB = std::max(1, std::min(OB, atoi(getenv("BIOEM_BATCH_ORIENTATIONS"))));
-  if (OB > nAngles)
-    OB = nAngles;
+  if (OB > angO1 - angO0)
+    OB = angO1 - angO0;
   h->OB = OB;
   h->maxOC = OB * nCTF;
   h->chunkB = OB > 32 ? OB : 32;
@@ -969,8 +992,9 @@ int bioem_hip_create(bioem_hip_handle *out, int device, const bioem_hip_param_de
                                        hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int) wide_lds_bytes(N, h->H, h->wideWPC, h->nyq)));
   }
-  h->probBytes = bioem_hip_prob_size(nMaps, nAngles, pd->writeAngles);
-  HIP_CHECK(h, hipMalloc(&h->dProb, h->probBytes));
+  h->devProbBytes = bioem_hip_prob_size(nMaps, angO1 - angO0, pd->writeAngles);
+  h->probBytes = shard ? bioem_hip_prob_size(nMaps, 0, 0) : h->devProbBytes;
+  HIP_CHECK(h, hipMalloc(&h->dProb, h->devProbBytes));
   {
     // projection/convolution are filler work: lowest priority so that comparison blocks win the CUs
     int prLow = 0, prHigh = 0;
@@ -1046,6 +1070,18 @@ int bioem_hip_create(bioem_hip_handle *out, int device, const bioem_hip_param_de
   return 0;
 }
 
+int bioem_hip_create(bioem_hip_handle *out, int device, const bioem_hip_param_device *pd, int nMaps, int nAngles,
+                     int nCTF, int algo)
+{
+  return create_impl(out, device, pd, nMaps, nAngles, nCTF, algo, false, 0, nAngles);
+}
+
+int bioem_hip_create_shard(bioem_hip_handle *out, int device, const bioem_hip_param_device *pd, int nMaps, int nAngles,
+                           int nCTF, int algo, int iOrientBegin, int iOrientEnd)
+{
+  return create_impl(out, device, pd, nMaps, nAngles, nCTF, algo, true, iOrientBegin, iOrientEnd);
+}
+
 int bioem_hip_destroy(bioem_hip_handle h)
 {
   if (!h)
@@ -1060,7 +1096,8 @@ int bioem_hip_destroy(bioem_hip_handle h)
                   h->dTw,      h->dTwD,     h->dDisp,     h->dLtab,    h->dTwk,     h->dProjReal, h->dTempDen,  h->dRowSpec, h->dSpecRef,
                   h->dScratch, h->dConv,    h->dParams,   h->dPartials, h->dProb,
                   h->dProjReal2, h->dTempDen2, h->dRowSpec2, h->dSpecRef2, h->dScratch2, h->dConv2, h->dParams2,
-                  h->dTnyq, h->dTwNyq, h->dPartTiles, h->dConvShift, h->dDispLocal, h->dRankOfRow, h->dTileCenter, h->dTileValid};
+                  h->dTnyq, h->dTwNyq, h->dPartTiles, h->dConvShift, h->dDispLocal, h->dRankOfRow, h->dTileCenter, h->dTileValid,
+                  h->dCand, h->dSend, h->dRecv, h->dMerged};
   for (void *p : ptrs)
     if (p)
       hipFree(p);
@@ -1187,6 +1224,12 @@ int bioem_hip_start_run(bioem_hip_handle h, const void *pProb_host)
 {
   HIP_CHECK(h, hipSetDevice(h->device));
   HIP_CHECK(h, hipMemcpyAsync(h->dProb, pProb_host, h->probBytes, hipMemcpyHostToDevice, h->stream));
+  if (h->shard && h->pd.writeAngles)
+  { // the shard's angle table is initialised where it lives (bioem.cpp:688-697)
+    bioem_hip_prob_angle *pang = reinterpret_cast<bioem_hip_prob_angle *>(h->dProb + sizeof(bioem_hip_prob_map) * h->nMaps);
+    hipLaunchKernelGGL(k_init_angles, dim3(1024), dim3(256), 0, h->stream, pang, (size_t) (h->angO1 - h->angO0) * h->nMaps);
+    HIP_CHECK(h, hipGetLastError());
+  }
   HIP_CHECK(h, hipStreamSynchronize(h->stream));
   return 0;
 }
@@ -1196,7 +1239,7 @@ int bioem_hip_compare(bioem_hip_handle h, int iPipeline, int iOrient, int iConvS
 {
   HIP_CHECK(h, hipSetDevice(h->device));
   const size_t M = (size_t) h->M;
-  if (maxParallelConv < 1 || maxParallelConv > nTotParallelConv || iOrient < 0 || iOrient >= h->nAngles ||
+  if (maxParallelConv < 1 || maxParallelConv > nTotParallelConv || iOrient < h->angO0 || iOrient >= h->angO1 ||
       iConvStart < 0 || iConvStart + maxParallelConv > h->nCTF)
   {
     h->err = "bioem_hip_compare: orientation / convolution range out of bounds";
@@ -1255,12 +1298,25 @@ int bioem_hip_compare(bioem_hip_handle h, int iPipeline, int iOrient, int iConvS
 
 int bioem_hip_project_convolve_compare(bioem_hip_handle h, int iOrientBegin, int iOrientEnd)
 {
+  return bioem_hip_project_convolve_compare_ctf(h, iOrientBegin, iOrientEnd, 0, h ? h->nCTF : 0);
+}
+
+int bioem_hip_project_convolve_compare_ctf(bioem_hip_handle h, int iOrientBegin, int iOrientEnd, int iConvBegin,
+                                           int iConvEnd)
+{
   HIP_CHECK(h, hipSetDevice(h->device));
-  if (!h->dPts || iOrientBegin < 0 || iOrientEnd > h->nAnglesUp || iOrientBegin > iOrientEnd)
+  if (!h->dPts || iOrientBegin < 0 || iOrientEnd > h->nAnglesUp || iOrientBegin > iOrientEnd || iConvBegin < 0 ||
+      iConvEnd > h->nCTF || iConvBegin >= iConvEnd)
   {
     h->err = "project_convolve_compare: model/orientations not uploaded or range invalid";
     return 2;
   }
+  if (iOrientBegin < iOrientEnd && (iOrientBegin < h->angO0 || iOrientEnd > h->angO1))
+  {
+    h->err = "project_convolve_compare: orientations outside the range this shard handle was created for";
+    return 2;
+  }
+  const int nC = iConvEnd - iConvBegin;
   if (compat_flush(h)) // rows staged through the reference-compatible entry go first (call order)
     return 1;
   // two-slot pipeline: projection + convolution of batch b+1 run on prepStream while batch b is compared
@@ -1277,7 +1333,7 @@ int bioem_hip_project_convolve_compare(bioem_hip_handle h, int iOrientBegin, int
     }
     if (project_batch(h, bb, h->prepStream, o0, nO))
       return 1;
-    if (convolve_batch(h, bb, h->prepStream, nO))
+    if (convolve_batch(h, bb, h->prepStream, nO, iConvBegin, nC))
       return 1;
     HIP_CHECK(h, hipEventRecord(h->prepDone[slot], h->prepStream));
     return 0;
@@ -1296,7 +1352,7 @@ int bioem_hip_project_convolve_compare(bioem_hip_handle h, int iOrientBegin, int
     if (b + 1 < nb && prep(b + 1))
       return 1;
     HIP_CHECK(h, hipStreamWaitEvent(h->stream, h->prepDone[slot], 0));
-    if (launch_compare_fold(h, batch_buf(h, slot), nO * h->nCTF, o0, 0, h->nCTF))
+    if (launch_compare_fold(h, batch_buf(h, slot), nO * nC, o0, iConvBegin, nC))
       return 1;
     HIP_CHECK(h, hipEventRecord(h->cmpDone[slot], h->stream));
     h->cmpPending[slot] = true;
@@ -1381,6 +1437,262 @@ int bioem_hip_merge_host(int nShards, int nMaps, int nAngles, int writeAngles, c
   return 0;
 }
 
+
+// ---- WRITE_PROB_ANGLES: K best orientations per particle, selected where the table lives ----
+static int topk_device(bioem_hip_ctx *h, int K, double numconst)
+{
+  if (!h->pd.writeAngles || K < 1)
+  {
+    h->err = "topk_angles: handle was created without WRITE_PROB_ANGLES or K < 1";
+    return 2;
+  }
+  if (h->candK != K)
+  {
+    if (h->dCand)
+      hipFree(h->dCand);
+    h->dCand = nullptr;
+    h->candK = 0;
+    HIP_CHECK(h, hipMalloc(&h->dCand, sizeof(bioem_hip_angle_candidate) * (size_t) h->nMaps * K));
+    h->candK = K;
+  }
+  const bioem_hip_prob_angle *pang =
+      reinterpret_cast<const bioem_hip_prob_angle *>(h->dProb + sizeof(bioem_hip_prob_map) * h->nMaps);
+  hipLaunchKernelGGL(k_topk_angles, dim3((h->nMaps + 63) / 64), dim3(64), 0, h->stream, pang, h->angO1 - h->angO0, h->nMaps,
+                     h->angO0, K, numconst, h->dCand);
+  HIP_CHECK(h, hipGetLastError());
+  return 0;
+}
+
+int bioem_hip_topk_angles(bioem_hip_handle h, int K, double numconst, bioem_hip_angle_candidate *out)
+{
+  HIP_CHECK(h, hipSetDevice(h->device));
+  if (compat_flush(h))
+    return 1;
+  if (const int rc = topk_device(h, K, numconst))
+    return rc;
+  HIP_CHECK(h, hipMemcpyAsync(out, h->dCand, sizeof(bioem_hip_angle_candidate) * (size_t) h->nMaps * K, hipMemcpyDeviceToHost,
+                              h->stream));
+  HIP_CHECK(h, hipStreamSynchronize(h->stream));
+  return 0;
+}
+
+int bioem_hip_merge_topk_host(int nShards, int nMaps, int K, const bioem_hip_angle_candidate *const *cands,
+                              bioem_hip_angle_candidate *out)
+{
+  if (nShards < 1 || K < 1)
+    return 2;
+  typedef std::pair<double, int> Item; // (logp, index into `all`): the reference's heap item with the orientation
+                                       // replaced by a position that is monotone in it
+  std::vector<bioem_hip_angle_candidate> all;
+  for (int i = 0; i < nMaps; i++)
+  {
+    all.clear();
+    for (int s = 0; s < nShards; s++)
+      for (int k = 0; k < K; k++)
+        if (cands[s][(size_t) i * K + k].orient >= 0)
+          all.push_back(cands[s][(size_t) i * K + k]);
+    // the writer walks the orientations in ascending order (bioem.cpp:1257)
+    std::sort(all.begin(), all.end(),
+              [](const bioem_hip_angle_candidate &a, const bioem_hip_angle_candidate &b) { return a.orient < b.orient; });
+    std::priority_queue<Item, std::vector<Item>, std::greater<Item>> q;
+    for (int j = 0; j < (int) all.size(); j++)
+    {
+      if ((int) q.size() < K)
+        q.push(Item(all[j].logp, j));
+      else if (q.top().first < all[j].logp)
+      {
+        q.pop();
+        q.push(Item(all[j].logp, j));
+      }
+    }
+    bioem_hip_angle_candidate *o = out + (size_t) i * K;
+    const int cnt = (int) q.size();
+    for (int r = cnt - 1; r >= 0; r--)
+    {
+      o[r] = all[q.top().second];
+      q.pop();
+    }
+    for (int r = cnt; r < K; r++)
+    {
+      o[r].forAngles = 0.;
+      o[r].ConstAngle = MIN_PROB;
+      o[r].logp = -INFINITY;
+      o[r].orient = -1;
+      o[r].pad = 0;
+    }
+  }
+  return 0;
+}
+
+// ---- RCCL merge (one process, n GPUs): librccl is large, so it is loaded when the first merge asks for it ----
+namespace
+{
+struct Rccl
+{
+  void *lib = nullptr;
+  ncclResult_t (*CommInitAll)(ncclComm_t *, int, const int *) = nullptr;
+  ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*GroupStart)() = nullptr;
+  ncclResult_t (*GroupEnd)() = nullptr;
+  const char *(*GetErrorString)(ncclResult_t) = nullptr;
+  std::map<std::vector<int>, std::vector<ncclComm_t>> comms; // by device list; kept for the life of the process
+  std::mutex mu;
+};
+Rccl g_rccl;
+
+const char *rccl_load()
+{
+  if (g_rccl.lib)
+    return nullptr;
+  const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+  void *lib = nullptr;
+  for (const char *n : names)
+    if ((lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL)))
+      break;
+  if (!lib)
+    return "librccl.so not found (needed for the multi-GPU merge)";
+  g_rccl.CommInitAll = (decltype(g_rccl.CommInitAll)) dlsym(lib, "ncclCommInitAll");
+  g_rccl.AllGather = (decltype(g_rccl.AllGather)) dlsym(lib, "ncclAllGather");
+  g_rccl.GroupStart = (decltype(g_rccl.GroupStart)) dlsym(lib, "ncclGroupStart");
+  g_rccl.GroupEnd = (decltype(g_rccl.GroupEnd)) dlsym(lib, "ncclGroupEnd");
+  g_rccl.GetErrorString = (decltype(g_rccl.GetErrorString)) dlsym(lib, "ncclGetErrorString");
+  if (!g_rccl.CommInitAll || !g_rccl.AllGather || !g_rccl.GroupStart || !g_rccl.GroupEnd || !g_rccl.GetErrorString)
+    return "librccl.so lacks ncclCommInitAll / ncclAllGather / ncclGroupStart / ncclGroupEnd";
+  g_rccl.lib = lib;
+  return nullptr;
+}
+} // namespace
+
+#define RCCL_CHECK(h, expr)                                                                                        \
+  do                                                                                                               \
+  {                                                                                                                \
+    ncclResult_t r_ = (expr);                                                                                      \
+    if (r_ != ncclSuccess)                                                                                         \
+    {                                                                                                              \
+      char buf_[512];                                                                                              \
+      snprintf(buf_, sizeof(buf_), "%s failed: %s (%s:%d)", #expr, g_rccl.GetErrorString(r_), __FILE__, __LINE__); \
+      (h)->err = buf_;                                                                                             \
+      return 1;                                                                                                    \
+    }                                                                                                              \
+  } while (0)
+
+int bioem_hip_merge(bioem_hip_handle *handles, int n, void *pProbMaps_host, int K, double numconst,
+                    bioem_hip_angle_candidate *cand_host)
+{
+  if (!handles || n < 1 || !handles[0])
+    return 2;
+  bioem_hip_ctx *h0 = handles[0];
+  const int nMaps = h0->nMaps;
+  std::vector<int> devs(n);
+  for (int i = 0; i < n; i++)
+  {
+    if (!handles[i] || handles[i]->nMaps != nMaps)
+    {
+      h0->err = "bioem_hip_merge: handles of different shape";
+      return 2;
+    }
+    devs[i] = handles[i]->device;
+    for (int j = 0; j < i; j++)
+      if (devs[j] == devs[i])
+      {
+        h0->err = "bioem_hip_merge: RCCL needs one GPU per shard (two handles share a device; use bioem_hip_merge_host)";
+        return 2;
+      }
+  }
+  if (K > 0 && !cand_host)
+    return 2;
+  std::lock_guard<std::mutex> lock(g_rccl.mu);
+  if (const char *e = rccl_load())
+  {
+    h0->err = e;
+    return 1;
+  }
+  auto it = g_rccl.comms.find(devs);
+  if (it == g_rccl.comms.end())
+  {
+    std::vector<ncclComm_t> c(n);
+    RCCL_CHECK(h0, g_rccl.CommInitAll(c.data(), n, devs.data()));
+    it = g_rccl.comms.emplace(devs, c).first;
+  }
+  const std::vector<ncclComm_t> &comm = it->second;
+  const size_t mapBytes = sizeof(bioem_hip_prob_map) * (size_t) nMaps;
+  const size_t payload = mapBytes + (K > 0 ? sizeof(bioem_hip_angle_candidate) * (size_t) nMaps * K : 0);
+  // stage every shard's contribution: its map entries (already on the device) and its K best orientations
+  for (int i = 0; i < n; i++)
+  {
+    bioem_hip_ctx *h = handles[i];
+    HIP_CHECK(h, hipSetDevice(h->device));
+    if (compat_flush(h))
+      return 1;
+    if (h->sendBytes < payload)
+    {
+      if (h->dSend)
+        hipFree(h->dSend);
+      h->dSend = nullptr;
+      h->sendBytes = 0;
+      HIP_CHECK(h, hipMalloc(&h->dSend, payload));
+      h->sendBytes = payload;
+    }
+    if (h->recvBytes < payload * n)
+    {
+      if (h->dRecv)
+        hipFree(h->dRecv);
+      h->dRecv = nullptr;
+      h->recvBytes = 0;
+      HIP_CHECK(h, hipMalloc(&h->dRecv, payload * n));
+      h->recvBytes = payload * n;
+    }
+    HIP_CHECK(h, hipMemcpyAsync(h->dSend, h->dProb, mapBytes, hipMemcpyDeviceToDevice, h->stream));
+    if (K > 0)
+    {
+      if (const int rc = topk_device(h, K, numconst))
+        return rc;
+      HIP_CHECK(h, hipMemcpyAsync(h->dSend + mapBytes, h->dCand, payload - mapBytes, hipMemcpyDeviceToDevice, h->stream));
+    }
+  }
+  // the exchange: one all-gather over xGMI
+  RCCL_CHECK(h0, g_rccl.GroupStart());
+  for (int i = 0; i < n; i++)
+  {
+    bioem_hip_ctx *h = handles[i];
+    HIP_CHECK(h, hipSetDevice(h->device));
+    RCCL_CHECK(h, g_rccl.AllGather(h->dSend, h->dRecv, payload, ncclChar, comm[i], h->stream));
+  }
+  RCCL_CHECK(h0, g_rccl.GroupEnd());
+  // fold on the first device, result to the host
+  HIP_CHECK(h0, hipSetDevice(h0->device));
+  if (!h0->dMerged)
+    HIP_CHECK(h0, hipMalloc(&h0->dMerged, mapBytes));
+  hipLaunchKernelGGL(k_merge_shards, dim3((nMaps + 127) / 128), dim3(128), 0, h0->stream, h0->dRecv, n, payload, nMaps,
+                     h0->dMerged);
+  HIP_CHECK(h0, hipGetLastError());
+  HIP_CHECK(h0, hipMemcpyAsync(pProbMaps_host, h0->dMerged, mapBytes, hipMemcpyDeviceToHost, h0->stream));
+  std::vector<std::vector<bioem_hip_angle_candidate>> gathered;
+  if (K > 0)
+  {
+    gathered.resize(n);
+    for (int s = 0; s < n; s++)
+    {
+      gathered[s].resize((size_t) nMaps * K);
+      HIP_CHECK(h0, hipMemcpyAsync(gathered[s].data(), h0->dRecv + (size_t) s * payload + mapBytes, payload - mapBytes,
+                                   hipMemcpyDeviceToHost, h0->stream));
+    }
+  }
+  for (int i = 0; i < n; i++)
+  {
+    HIP_CHECK(handles[i], hipSetDevice(handles[i]->device));
+    HIP_CHECK(handles[i], hipStreamSynchronize(handles[i]->stream));
+  }
+  if (K > 0)
+  {
+    std::vector<const bioem_hip_angle_candidate *> ptrs(n);
+    for (int s = 0; s < n; s++)
+      ptrs[s] = gathered[s].data();
+    return bioem_hip_merge_topk_host(n, nMaps, K, ptrs.data(), cand_host);
+  }
+  return 0;
+}
+
 int bioem_hip_debug_projection(bioem_hip_handle h, int iOrient, float *spec_out)
 {
   HIP_CHECK(h, hipSetDevice(h->device));
@@ -1397,7 +1709,7 @@ int bioem_hip_debug_convolution(bioem_hip_handle h, int iOrient, int iConv, floa
   HIP_CHECK(h, hipSetDevice(h->device));
   if (project_batch(h, batch_buf(h, 0), h->stream, iOrient, 1))
     return 1;
-  if (convolve_batch(h, batch_buf(h, 0), h->stream, 1))
+  if (convolve_batch(h, batch_buf(h, 0), h->stream, 1, 0, h->nCTF))
     return 1;
   const size_t M = (size_t) h->M;
   float2 *tmp = h->dSpecRef + M; // chunkB >= 32 slots; slot 0 holds the projection spectrum

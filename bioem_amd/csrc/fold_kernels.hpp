@@ -14,7 +14,7 @@ __global__ void k_fold(const Partial *__restrict__ partials, int ldPart, int nOC
                        const bioem_hip_param5 *__restrict__ params, const float *__restrict__ sumRef,
                        const int *__restrict__ disp, int nd, PD pd, int orient0, int conv0, int convPerOrient,
                        const int2 *__restrict__ ids, bioem_hip_prob_map *__restrict__ pmap,
-                       bioem_hip_prob_angle *__restrict__ pang)
+                       bioem_hip_prob_angle *__restrict__ pang, int angO0)
 {
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= nMaps)
@@ -45,14 +45,14 @@ __global__ void k_fold(const Partial *__restrict__ partials, int ldPart, int nOC
     pm.Total += r.sumExp * exp(lp - pm.Constoadd);
     if (pd.writeAngles)
     {
-      bioem_hip_prob_angle pa = pang[(size_t) iOrient * nMaps + p];
+      bioem_hip_prob_angle pa = pang[(size_t) (iOrient - angO0) * nMaps + p];
       if (pa.ConstAngle < lp)
       {
         pa.forAngles *= exp(-lp + pa.ConstAngle);
         pa.ConstAngle = lp;
       }
       pa.forAngles += r.sumExp * exp(lp - pa.ConstAngle);
-      pang[(size_t) iOrient * nMaps + p] = pa;
+      pang[(size_t) (iOrient - angO0) * nMaps + p] = pa;
     }
   }
   pmap[p] = pm;
@@ -67,7 +67,7 @@ __global__ void k_fold(const Partial *__restrict__ partials, int ldPart, int nOC
 // ------------------------------------------------------------------------------------------------
 __global__ void k_fold_angles(const Partial *__restrict__ partials, int ldPart, int nOC, int nMaps, int orient0,
                               int convPerOrient, const int4 *__restrict__ segs, int nRuns,
-                              bioem_hip_prob_angle *__restrict__ pang)
+                              bioem_hip_prob_angle *__restrict__ pang, int angO0)
 {
   const long long t = (long long) blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= (long long) nRuns * nMaps)
@@ -82,7 +82,8 @@ __global__ void k_fold_angles(const Partial *__restrict__ partials, int ldPart, 
     ocEnd = sg.y;
     iOrient = sg.z;
   }
-  bioem_hip_prob_angle pa = pang[(size_t) iOrient * nMaps + p];
+  // the table holds the orientations [angO0, ...) this handle owns (all of them unless it is a shard)
+  bioem_hip_prob_angle pa = pang[(size_t) (iOrient - angO0) * nMaps + p];
   for (int oc = ocBegin; oc < ocEnd; oc++)
   {
     const Partial r = P[oc];
@@ -94,7 +95,7 @@ __global__ void k_fold_angles(const Partial *__restrict__ partials, int ldPart, 
     }
     pa.forAngles += r.sumExp * exp(lp - pa.ConstAngle);
   }
-  pang[(size_t) iOrient * nMaps + p] = pa;
+  pang[(size_t) (iOrient - angO0) * nMaps + p] = pa;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -167,6 +168,146 @@ __global__ __launch_bounds__(256) void k_fold_wave(const Partial *__restrict__ p
     pm.Total += sacc * exp(m - pm.Constoadd);
     pmap[p] = pm;
   }
+}
+
+// ------------------------------------------------------------------------------------------------
+// shard handles: the angle table never leaves the device
+// ------------------------------------------------------------------------------------------------
+__global__ void k_init_angles(bioem_hip_prob_angle *__restrict__ pang, size_t n)
+{ // bioem.cpp:688-697
+  for (size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t) gridDim.x * blockDim.x)
+  {
+    bioem_hip_prob_angle a;
+    a.forAngles = 0.0;
+    a.ConstAngle = MIN_PROB;
+    pang[i] = a;
+  }
+}
+
+// order of the reference's std::pair<double, int> heap items (bioem.cpp:1254-1256)
+__host__ __device__ inline bool cand_less(double la, int ia, double lb, int ib)
+{
+  return la < lb || (la == lb && ia < ib);
+}
+
+// K best orientations per particle among the nO owned ones, by the reference writer's own rule (bioem.cpp:1251-1286):
+// walk the orientations in order; fill a K-entry set; afterwards an entry replaces the set's minimum (by (logp,
+// orientation)) when the minimum's logp is strictly below its own.  One thread per particle: the table is
+// orientation-major, so the 64 particles of a wave read consecutive 16-byte entries of one orientation row.  The set
+// lives in the thread's K output slots; replacements are rare (~K ln(nO/K) per particle), each followed by a scan
+// of the K slots for the new minimum.  Output sorted best first (descending (logp, orientation), the order in which
+// the reference prints after emptying its heap).
+__global__ void k_topk_angles(const bioem_hip_prob_angle *__restrict__ pang, int nO, int nMaps, int o0, int K,
+                              double numconst, bioem_hip_angle_candidate *__restrict__ out)
+{
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= nMaps)
+    return;
+  bioem_hip_angle_candidate *mine = out + (size_t) p * K;
+  int cnt = 0, minSlot = 0;
+  double minLogp = 0.;
+  int minIo = 0;
+  for (int io = 0; io < nO; io++)
+  {
+    const bioem_hip_prob_angle pa = pang[(size_t) io * nMaps + p];
+    const double logp = log(pa.forAngles) + pa.ConstAngle + numconst;
+    bool rescan = false;
+    if (cnt < K)
+    {
+      bioem_hip_angle_candidate c;
+      c.forAngles = pa.forAngles;
+      c.ConstAngle = pa.ConstAngle;
+      c.logp = logp;
+      c.orient = o0 + io;
+      c.pad = 0;
+      mine[cnt++] = c;
+      rescan = cnt == K;
+    }
+    else if (minLogp < logp)
+    {
+      bioem_hip_angle_candidate c;
+      c.forAngles = pa.forAngles;
+      c.ConstAngle = pa.ConstAngle;
+      c.logp = logp;
+      c.orient = o0 + io;
+      c.pad = 0;
+      mine[minSlot] = c;
+      rescan = true;
+    }
+    if (rescan)
+    {
+      minSlot = 0;
+      minLogp = mine[0].logp;
+      minIo = mine[0].orient;
+      for (int j = 1; j < K; j++)
+      {
+        const double l = mine[j].logp;
+        const int i = mine[j].orient;
+        if (cand_less(l, i, minLogp, minIo))
+        {
+          minSlot = j;
+          minLogp = l;
+          minIo = i;
+        }
+      }
+    }
+  }
+  // best first
+  for (int a = 0; a < cnt; a++)
+  {
+    int best = a;
+    for (int b = a + 1; b < cnt; b++)
+      if (cand_less(mine[best].logp, mine[best].orient, mine[b].logp, mine[b].orient))
+        best = b;
+    if (best != a)
+    {
+      const bioem_hip_angle_candidate t = mine[a];
+      mine[a] = mine[best];
+      mine[best] = t;
+    }
+  }
+  for (int a = cnt; a < K; a++)
+  {
+    bioem_hip_angle_candidate c;
+    c.forAngles = 0.;
+    c.ConstAngle = MIN_PROB;
+    c.logp = -INFINITY;
+    c.orient = -1;
+    c.pad = 0;
+    mine[a] = c;
+  }
+}
+
+// fold of the gathered shards' map entries (bioem.cpp:909-994 restated for one address space): shard s's entries start
+// at gathered + s * stride bytes.  Maximum Constoadd wins; ties go to the LOWEST shard (= lowest orientation block,
+// the serial first-maximum semantics); Total = sum over shards of Total_s * exp(Constoadd_s - max), in shard order.
+__global__ void k_merge_shards(const unsigned char *__restrict__ gathered, int nShards, size_t stride, int nMaps,
+                               bioem_hip_prob_map *__restrict__ out)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nMaps)
+    return;
+  int who = 0;
+  double cmax = reinterpret_cast<const bioem_hip_prob_map *>(gathered)[i].Constoadd;
+  for (int s = 1; s < nShards; s++)
+  {
+    const double c = reinterpret_cast<const bioem_hip_prob_map *>(gathered + (size_t) s * stride)[i].Constoadd;
+    if (c > cmax)
+    {
+      cmax = c;
+      who = s;
+    }
+  }
+  double tot = 0.;
+  for (int s = 0; s < nShards; s++)
+  {
+    const bioem_hip_prob_map m = reinterpret_cast<const bioem_hip_prob_map *>(gathered + (size_t) s * stride)[i];
+    tot += m.Total * exp(m.Constoadd - cmax);
+  }
+  bioem_hip_prob_map o = reinterpret_cast<const bioem_hip_prob_map *>(gathered + (size_t) who * stride)[i];
+  o.Total = tot;
+  o.Constoadd = cmax;
+  out[i] = o;
 }
 
 } // namespace

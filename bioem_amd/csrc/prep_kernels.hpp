@@ -296,19 +296,19 @@ __global__ void k_map_sums(const float *__restrict__ maps, int NN, float *__rest
 }
 
 // ------------------------------------------------------------------------------------------------
-// convolution: bioem.cpp:1855-1923.  grid (nCTF, nOrientInBatch).
+// convolution: bioem.cpp:1855-1923.  grid (CTFs of the launch, nOrientInBatch); CTF index = c0 + blockIdx.x.
 // sumsquareC is accumulated sequentially in float in the reference's order (rows; inside a row the
 // interior columns doubled, then column 0, then column N/2 for even N): the terms are produced in
 // parallel into `scratch` in that order and summed by one lane.
 // ------------------------------------------------------------------------------------------------
 __global__ void k_convolve(const float2 *__restrict__ proj, const float2 *__restrict__ ctf,
-                           const float *__restrict__ ctfParam, int N, int H, int fast, int N1, int nCTF,
+                           const float *__restrict__ ctfParam, int N, int H, int fast, int N1, int c0,
                            float2 *__restrict__ conv, float *__restrict__ scratch,
                            bioem_hip_param5 *__restrict__ params)
 {
   __shared__ float buf[4096];
-  const int c = blockIdx.x, ob = blockIdx.y;
-  const int oc = ob * nCTF + c;
+  const int c = c0 + blockIdx.x, ob = blockIdx.y;
+  const int oc = ob * gridDim.x + blockIdx.x;
   const int M = N * H;
   const float2 *P = proj + (size_t) ob * M;
   const float2 *K = ctf + (size_t) c * M;

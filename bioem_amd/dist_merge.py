@@ -1,48 +1,53 @@
-"""Shard merge over torch.distributed (backend "nccl" = RCCL over xGMI on the GPU box, "gloo" in CPU tests).
+"""Shard merge over torch.distributed for one-process-per-GPU runs (backend "nccl" = RCCL over xGMI on the GPU box,
+"gloo" in the CPU tests).  The in-process counterpart (n GPUs, one process) is bioem_hip_merge in the C ABI.
 
-Orientation blocks are independent; the only exchange step of the path is the log-sum-exp merge of the
-per-particle posteriors at the end of a run (reference: MPI merge, bioem.cpp:909-1044):
-    C*      = all_reduce_max(Constoadd)
-    Total*  = all_reduce_sum(Total * exp(Constoadd - C*))
-    arg-max = the entry of the LOWEST rank holding C* (lowest orientation block = serial first-maximum
-              semantics; the reference's MPI path takes the highest rank, bioem.cpp:946-949)
-Three small collectives (8 B, 8 B and 32 B per particle): latency-bound, no data-path collective.
+Orientation blocks are independent; the only exchange step of the path is the merge of the per-particle posteriors at
+the end of a run (reference: MPI merge, bioem.cpp:909-1044).  Every rank contributes its nMaps 40-byte map entries --
+and, with WRITE_PROB_ANGLES, its K best orientations per particle (32 bytes each, selected on the device by
+bioem_hip_topk_angles: each orientation has one owner, so the angle table itself needs no reduction) -- to ONE
+all-gather; every rank then folds the gathered shards with the same rule as bioem_hip_merge_host:
+    C*      = max_s Constoadd_s
+    Total*  = sum_s Total_s * exp(Constoadd_s - C*)            (rank order)
+    arg-max = the record of the LOWEST rank holding C* (lowest orientation block = serial first-maximum semantics;
+              the reference's MPI path takes the highest rank, bioem.cpp:946-949)
+    angles  = the K best of the union of the ranks' candidates (the writer's min-heap rule, bioem.cpp:1251-1286)
+400 KB (+ 3.2 MB of candidates at K = 10) per rank at 10 000 particles: latency-bound, xGMI bandwidth irrelevant.
 """
 import numpy as np
 import torch
 import torch.distributed as dist
 
-from .engine import PROB_MAP_DTYPE
+from .engine import CANDIDATE_DTYPE, PROB_MAP_DTYPE, merge_host, merge_topk_host
 
 
-def merge_prob_maps(pmap, device, group=None):
-    """pmap: this rank's numpy PROB_MAP_DTYPE array.  Returns the merged array (identical on every rank)."""
+def merge_prob_maps(pmap, device, orient_offset=0, cands=None, group=None):
+    """pmap: this rank's numpy PROB_MAP_DTYPE array; orient_offset is added to its arg-max orientation indices (for
+    engines that number their own block from 0; engines created as shards of the global list pass 0); cands: this
+    rank's [nMaps, K] CANDIDATE_DTYPE array or None.  Returns the merged pmap (and the merged candidates if cands is
+    given), identical on every rank."""
     world = dist.get_world_size(group)
-    rank = dist.get_rank(group)
     n = len(pmap)
-    const = torch.from_numpy(np.ascontiguousarray(pmap["Constoadd"])).to(device)
-    total = torch.from_numpy(np.ascontiguousarray(pmap["Total"])).to(device)
-    cmax = const.clone()
-    dist.all_reduce(cmax, op=dist.ReduceOp.MAX, group=group)
-    tsum = total * torch.exp(const - cmax)
-    dist.all_reduce(tsum, op=dist.ReduceOp.SUM, group=group)
-    owner = torch.where(const >= cmax, torch.full((n,), rank, dtype=torch.int64, device=device),
-                        torch.full((n,), world, dtype=torch.int64, device=device))
-    dist.all_reduce(owner, op=dist.ReduceOp.MIN, group=group)
-    # ship the 24-byte arg-max records of the owners: masked sum (exactly one contributor per particle)
-    rec = np.zeros((n, 6), dtype=np.int32)
-    rec[:, 0], rec[:, 1], rec[:, 2], rec[:, 3] = pmap["cent_x"], pmap["cent_y"], pmap["orient"], pmap["conv"]
-    rec[:, 4] = pmap["norm"].view(np.int32)
-    rec[:, 5] = pmap["mu"].view(np.int32)
-    trec = torch.from_numpy(rec).to(device).to(torch.int64)
-    mine = (owner == rank).unsqueeze(1)
-    trec = torch.where(mine, trec, torch.zeros_like(trec))
-    dist.all_reduce(trec, op=dist.ReduceOp.SUM, group=group)
-    out = np.zeros(n, dtype=PROB_MAP_DTYPE)
-    out["Total"] = tsum.cpu().numpy()
-    out["Constoadd"] = cmax.cpu().numpy()
-    r = trec.cpu().numpy().astype(np.int32)
-    out["cent_x"], out["cent_y"], out["orient"], out["conv"] = r[:, 0], r[:, 1], r[:, 2], r[:, 3]
-    out["norm"] = r[:, 4].copy().view(np.float32)
-    out["mu"] = r[:, 5].copy().view(np.float32)
-    return out
+    mine = np.array(pmap, dtype=PROB_MAP_DTYPE, copy=True)
+    if orient_offset:
+        mine["orient"] += np.int32(orient_offset)
+    parts = [mine.view(np.uint8).reshape(-1)]
+    K = 0
+    if cands is not None:
+        c = np.array(cands, dtype=CANDIDATE_DTYPE, copy=True)
+        assert c.shape[0] == n
+        K = c.shape[1]
+        if orient_offset:
+            c["orient"] = np.where(c["orient"] >= 0, c["orient"] + np.int32(orient_offset), c["orient"])
+        parts.append(c.view(np.uint8).reshape(-1))
+    payload = np.concatenate(parts)
+    send = torch.from_numpy(payload).to(device)
+    recv = torch.empty(world * payload.size, dtype=torch.uint8, device=device)
+    dist.all_gather_into_tensor(recv, send, group=group)          # the exchange step
+    got = recv.cpu().numpy().reshape(world, payload.size)
+    map_bytes = n * PROB_MAP_DTYPE.itemsize
+    blocks = [np.ascontiguousarray(got[r, :map_bytes]) for r in range(world)]
+    merged = merge_host(blocks, n, 0, 0).view(PROB_MAP_DTYPE)
+    if cands is None:
+        return merged
+    lists = [np.ascontiguousarray(got[r, map_bytes:]).view(CANDIDATE_DTYPE).reshape(n, K) for r in range(world)]
+    return merged, merge_topk_host(lists)

@@ -12,6 +12,8 @@ PROB_MAP_DTYPE = np.dtype([("Total", "<f8"), ("Constoadd", "<f8"), ("cent_x", "<
 PROB_ANGLE_DTYPE = np.dtype([("forAngles", "<f8"), ("ConstAngle", "<f8")])
 PARAM5_DTYPE = np.dtype([("amp", "<f4"), ("pha", "<f4"), ("env", "<f4"), ("sumC", "<f4"), ("sumsquareC", "<f4")])
 POINT_DTYPE = np.dtype([("pos", "<f4", (3,)), ("quat4", "<f4"), ("radius", "<f4"), ("density", "<f4")])
+CANDIDATE_DTYPE = np.dtype([("forAngles", "<f8"), ("ConstAngle", "<f8"), ("logp", "<f8"), ("orient", "<i4"),
+                            ("pad", "<i4")])
 MIN_PROB = -999999.0
 
 
@@ -44,6 +46,7 @@ def load_library():
     vp, ci, cf = C.c_void_p, C.c_int, C.c_float
     L.bioem_hip_device_count.restype = ci
     L.bioem_hip_create.argtypes = [C.POINTER(vp), ci, C.POINTER(ParamDevice), ci, ci, ci, ci]
+    L.bioem_hip_create_shard.argtypes = [C.POINTER(vp), ci, C.POINTER(ParamDevice), ci, ci, ci, ci, ci, ci]
     L.bioem_hip_destroy.argtypes = [vp]
     L.bioem_hip_last_error.argtypes = [vp]
     L.bioem_hip_last_error.restype = C.c_char_p
@@ -60,7 +63,11 @@ def load_library():
     L.bioem_hip_start_run.argtypes = [vp, vp]
     L.bioem_hip_compare.argtypes = [vp, ci, ci, ci, ci, ci, vp, vp]
     L.bioem_hip_project_convolve_compare.argtypes = [vp, ci, ci]
+    L.bioem_hip_project_convolve_compare_ctf.argtypes = [vp, ci, ci, ci, ci]
     L.bioem_hip_finish_run.argtypes = [vp, vp]
+    L.bioem_hip_topk_angles.argtypes = [vp, ci, C.c_double, vp]
+    L.bioem_hip_merge_topk_host.argtypes = [ci, ci, ci, C.POINTER(vp), vp]
+    L.bioem_hip_merge.argtypes = [C.POINTER(vp), ci, vp, ci, C.c_double, vp]
     L.bioem_hip_merge_host.argtypes = [ci, ci, ci, ci, C.POINTER(vp), vp]
     L.bioem_hip_debug_projection.argtypes = [vp, ci, vp]
     L.bioem_hip_debug_convolution.argtypes = [vp, ci, ci, vp, C.POINTER(cf), C.POINTER(cf)]
@@ -76,7 +83,9 @@ def load_library():
     return L
 
 
-EXPORTS = ["bioem_hip_device_count", "bioem_hip_create", "bioem_hip_destroy", "bioem_hip_last_error",
+EXPORTS = ["bioem_hip_device_count", "bioem_hip_create", "bioem_hip_create_shard", "bioem_hip_destroy",
+           "bioem_hip_last_error", "bioem_hip_project_convolve_compare_ctf", "bioem_hip_topk_angles",
+           "bioem_hip_merge_topk_host", "bioem_hip_merge",
            "bioem_hip_upload_particles", "bioem_hip_upload_particle_maps", "bioem_hip_upload_ctf",
            "bioem_hip_upload_model", "bioem_hip_upload_orientations", "bioem_hip_host_alloc",
            "bioem_hip_host_free", "bioem_hip_prob_size", "bioem_hip_start_run", "bioem_hip_compare",
@@ -111,14 +120,21 @@ class Engine:
     """One GPU's comparison engine; method names mirror the plugin hooks of the reference
     (deviceInit / deviceStartRun / compareRefMaps / deviceFinishRun, include/bioem.h:52-79)."""
 
-    def __init__(self, pd, nMaps, nAngles, nCTF, algo=1, device=0):
+    def __init__(self, pd, nMaps, nAngles, nCTF, algo=1, device=0, shard=None):
+        """shard = (iOrientBegin, iOrientEnd): bioem_hip_create_shard -- the handle owns that block of the nAngles
+        global orientations, keeps its angle table on the device and moves only the map entries in start/finish_run."""
         self.L = load_library()
         self.h = C.c_void_p()
         self.pd = pd
         self.nMaps, self.nAngles, self.nCTF, self.algo = nMaps, nAngles, nCTF, algo
         self.N = pd.NumberPixels
         self.H = self.N // 2 + 1
-        rc = self.L.bioem_hip_create(C.byref(self.h), device, C.byref(pd), nMaps, nAngles, nCTF, algo)
+        self.shard = shard
+        if shard is None:
+            rc = self.L.bioem_hip_create(C.byref(self.h), device, C.byref(pd), nMaps, nAngles, nCTF, algo)
+        else:
+            rc = self.L.bioem_hip_create_shard(C.byref(self.h), device, C.byref(pd), nMaps, nAngles, nCTF, algo,
+                                               int(shard[0]), int(shard[1]))
         if rc:
             msg = self.L.bioem_hip_last_error(self.h).decode() if self.h else "create failed"
             raise RuntimeError("bioem_hip_create: " + msg)
@@ -176,8 +192,14 @@ class Engine:
         self._chk(self.L.bioem_hip_upload_orientations(self.h, _p(angles), len(angles), int(bool(isQuat))),
                   "upload_orientations")
 
+    def prob_bytes(self):
+        """bytes start_run / finish_run move: the whole block, or only the map entries for a shard handle"""
+        if self.shard is not None:
+            return self.L.bioem_hip_prob_size(self.nMaps, 0, 0)
+        return self.L.bioem_hip_prob_size(self.nMaps, self.nAngles, self.pd.writeAngles)
+
     def start_run(self, raw):
-        assert raw.nbytes == self.L.bioem_hip_prob_size(self.nMaps, self.nAngles, self.pd.writeAngles)
+        assert raw.nbytes == self.prob_bytes()
         self._chk(self.L.bioem_hip_start_run(self.h, _p(raw)), "start_run")
 
     def compare(self, iPipeline, iOrient, iConvStart, maxParallelConv, nTotParallelConv, conv_base, params_base):
@@ -190,8 +212,18 @@ class Engine:
     def project_convolve_compare(self, o0, o1):
         self._chk(self.L.bioem_hip_project_convolve_compare(self.h, o0, o1), "project_convolve_compare")
 
+    def project_convolve_compare_ctf(self, o0, o1, c0, c1):
+        self._chk(self.L.bioem_hip_project_convolve_compare_ctf(self.h, o0, o1, c0, c1), "project_convolve_compare_ctf")
+
     def finish_run(self, raw):
+        assert raw.nbytes == self.prob_bytes()
         self._chk(self.L.bioem_hip_finish_run(self.h, _p(raw)), "finish_run")
+
+    def topk_angles(self, K, numconst):
+        """K best orientations per particle among the owned ones, selected on the device: [nMaps, K] CANDIDATE_DTYPE"""
+        out = np.zeros((self.nMaps, K), dtype=CANDIDATE_DTYPE)
+        self._chk(self.L.bioem_hip_topk_angles(self.h, K, float(numconst), _p(out)), "topk_angles")
+        return out
 
     def synchronize(self):
         self._chk(self.L.bioem_hip_synchronize(self.h), "synchronize")
@@ -222,6 +254,32 @@ class Engine:
 
     def reset_kernel_stats(self):
         self._chk(self.L.bioem_hip_reset_kernel_stats(self.h), "reset_kernel_stats")
+
+
+def merge_topk_host(cands):
+    """K-way merge of per-shard candidate lists ([nMaps, K] each, shards in ascending orientation-block order)."""
+    L = load_library()
+    nMaps, K = cands[0].shape
+    cands = [np.ascontiguousarray(c, dtype=CANDIDATE_DTYPE) for c in cands]
+    out = np.zeros((nMaps, K), dtype=CANDIDATE_DTYPE)
+    arr = (C.c_void_p * len(cands))(*[c.ctypes.data for c in cands])
+    if L.bioem_hip_merge_topk_host(len(cands), nMaps, K, arr, _p(out)):
+        raise RuntimeError("bioem_hip_merge_topk_host failed")
+    return out
+
+
+def merge_rccl(engines, K=0, numconst=0.0):
+    """bioem_hip_merge: RCCL all-gather + device fold of the engines' shards (one GPU per engine, this process).
+    Returns (pmap [nMaps], candidates [nMaps, K] or None)."""
+    L = load_library()
+    nMaps = engines[0].nMaps
+    pmap = np.zeros(nMaps, dtype=PROB_MAP_DTYPE)
+    cand = np.zeros((nMaps, K), dtype=CANDIDATE_DTYPE) if K > 0 else None
+    arr = (C.c_void_p * len(engines))(*[e.h.value for e in engines])
+    rc = L.bioem_hip_merge(arr, len(engines), _p(pmap), K, float(numconst), _p(cand))
+    if rc:
+        raise RuntimeError("bioem_hip_merge: " + L.bioem_hip_last_error(engines[0].h).decode())
+    return pmap, cand
 
 
 def merge_host(blocks, nMaps, nAngles, writeAngles):

@@ -111,17 +111,29 @@ public:
   Model model;
   ParticleStack particles;
   std::string outfileName = "Output_Probabilities";
-  std::vector<unsigned char> prob; // merged probability block
+  std::vector<unsigned char> prob;              // merged map entries [nMaps]
+  std::vector<bioem_hip_angle_candidate> cand;  // merged K best orientations [nMaps][K] (WRITE_PROB_ANGLES)
 
   int algo = 1;
   int debugOutput = 0;
-  int nGpus = 1;
+  int nGpus = 1;     // number of shards
+  int firstDev = 0;  // GPUDEVICE
+  bool splitCTF = false; // fewer orientations than shards: (orientation, CTF) pairs are split instead
+  bool useRccl = false;  // one GPU per shard: the merge runs over RCCL (bioem_hip_merge)
 
 private:
+  // one unit of the run: orientations [o0, o1) (and, with the CTF split, the run [u0, u1) of orientation-major
+  // (orientation, CTF) pairs) on one device, with a private probability block
+  struct Shard
+  {
+    bioem_hip_handle h = nullptr;
+    int device = 0, o0 = 0, o1 = 0;
+    long long u0 = 0, u1 = 0;
+    void *prob = nullptr;
+  };
   int readOptions(int argc, char **argv);
   void writeOutput();
-  std::vector<bioem_hip_handle> handles;
-  std::vector<void *> shardProb;
+  std::vector<Shard> shards;
 };
 
 } // namespace bioem_host

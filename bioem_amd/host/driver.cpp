@@ -24,9 +24,24 @@ namespace
 {
 void r2c_on_device(void *ctx, int N, const float *in, float *out)
 {
-  (void) ctx;
-  if (bioem_hip_r2c(0, N, 1, in, out))
+  const int device = ctx ? *static_cast<const int *>(ctx) : 0; // the device the run itself uses (GPUDEVICE)
+  if (bioem_hip_r2c(device, N, 1, in, out))
     fatal("device r2c failed");
+}
+
+// The reference's performance knobs (bioem.cpp:99-135, bioem_cuda.cu:216-222) balance a GPU against CPU cores and tune
+// its CUDA kernels.  A job script written for the reference may set any of them: they are read, reported and have
+// no effect here -- every comparison runs on the device (there is no CPU path to share the work with), the kernels
+// pick their own launch shapes, projection and convolution are batched on the device.
+void report_reference_knobs()
+{
+  static const char *const knobs[] = {"GPUWORKLOAD", "GPUASYNC", "GPUDUALSTREAM", "BIOEM_CUDA_THREAD_COUNT",
+                                      "BIOEM_PROJ_CONV_AT_ONCE", "OMP_NUM_THREADS"};
+  for (const char *k : knobs)
+    if (getenv(k))
+      printf("Note - %s=%s accepted, no effect (100 %% of the comparisons run on the device)\n", k, getenv(k));
+  if (getenv("GPU") && atoi(getenv("GPU")) == 0)
+    printf("Note - GPU=0 accepted, no effect: this engine has no CPU path, the run uses the device\n");
 }
 
 void check(bioem_hip_handle h, int rc, const char *what)
@@ -179,7 +194,28 @@ int Driver::configure(int ac, char **av)
   const int ndev = bioem_hip_device_count();
   if (ndev < 1)
     fatal("No HIP device found: this engine has no CPU path");
+  report_reference_knobs();
+  nGpus = ndev;
+  if (getenv("BIOEM_GPUS"))
+    nGpus = std::max(1, std::min(ndev, atoi(getenv("BIOEM_GPUS"))));
+  // BIOEM_SHARDS=n: n shards dealt round-robin over the selected GPUs (default: one per GPU); more shards than GPUs
+  // is only useful to rehearse the multi-GPU control flow and merge on a smaller machine
+  int nDevUsed = nGpus;
+  int nShards = nGpus;
+  if (getenv("BIOEM_SHARDS"))
+    nShards = std::max(1, atoi(getenv("BIOEM_SHARDS")));
+  firstDev = 0;
+  if (getenv("GPUDEVICE") && atoi(getenv("GPUDEVICE")) >= 0) // bioem_cuda.cu:719-732
+  {
+    firstDev = atoi(getenv("GPUDEVICE"));
+    if (!getenv("BIOEM_SHARDS"))
+      nShards = 1;
+    nDevUsed = 1;
+    if (firstDev >= ndev)
+      fatal("GPUDEVICE %d out of range (%d devices)", firstDev, ndev);
+  }
   param.r2c = r2c_on_device;
+  param.r2c_ctx = &firstDev;
   param.calculateRefCTF();
   if (getenv("BIOEM_DEBUG_BREAK")) // bioem.cpp:518-525: after volu was computed with the full counts
   {
@@ -189,59 +225,71 @@ int Driver::configure(int ac, char **av)
     if (param.nTotCTFs > cut)
       param.nTotCTFs = cut;
   }
-  nGpus = ndev;
-  if (getenv("BIOEM_GPUS"))
-    nGpus = std::max(1, std::min(ndev, atoi(getenv("BIOEM_GPUS"))));
-  // BIOEM_SHARDS=n: n orientation shards dealt round-robin over the selected GPUs (default: one per GPU); more
-  // shards than GPUs is only useful to rehearse the multi-GPU control flow and merge on a smaller machine
-  int nDevUsed = nGpus;
-  if (getenv("BIOEM_SHARDS"))
-    nGpus = std::max(1, atoi(getenv("BIOEM_SHARDS")));
-  if (nGpus > param.nTotGridAngles)
-    nGpus = param.nTotGridAngles;
-  nDevUsed = std::min(nDevUsed, nGpus);
-  int firstDev = 0;
-  if (getenv("GPUDEVICE") && atoi(getenv("GPUDEVICE")) >= 0) // bioem_cuda.cu:719-732
-  {
-    firstDev = atoi(getenv("GPUDEVICE"));
-    if (!getenv("BIOEM_SHARDS"))
-      nGpus = 1;
-    nDevUsed = 1;
-    if (firstDev >= ndev)
-      fatal("GPUDEVICE %d out of range (%d devices)", firstDev, ndev);
-  }
+  // Work split (north_star: "orientations x CTF-envelope grid shard"): orientation blocks as the reference's MPI ranks
+  // (bioem.cpp:748-753); with fewer orientations than shards the (orientation, CTF) pairs are split instead, in the
+  // serial visiting order (orientation outer, CTF inner), so that shard s still precedes shard s+1
+  const int nA = param.nTotGridAngles, nC = param.nTotCTFs;
+  splitCTF = nShards > nA;
+  if (splitCTF && (long long) nShards > (long long) nA * nC)
+    nShards = nA * nC;
+  nGpus = nShards;
+  nDevUsed = std::min(nDevUsed, nShards);
   const int nMaps = particles.ntot;
-  handles.assign(nGpus, nullptr);
-  for (int g = 0; g < nGpus; g++)
+  shards.assign(nShards, Shard());
+  for (int g = 0; g < nShards; g++)
   {
+    Shard &sh = shards[g];
+    sh.device = firstDev + g % nDevUsed;
+    if (!splitCTF)
+    {
+      sh.o0 = (int) ((long long) g * nA / nShards);
+      sh.o1 = (int) ((long long) (g + 1) * nA / nShards);
+      sh.u0 = (long long) sh.o0 * nC;
+      sh.u1 = (long long) sh.o1 * nC;
+    }
+    else
+    {
+      sh.u0 = (long long) g * nA * nC / nShards;
+      sh.u1 = (long long) (g + 1) * nA * nC / nShards;
+      sh.o0 = (int) (sh.u0 / nC);
+      sh.o1 = (int) ((sh.u1 + nC - 1) / nC);
+    }
     bioem_hip_handle h = nullptr;
-    const int rc = bioem_hip_create(&h, firstDev + g % nDevUsed, &param.pd, nMaps, param.nTotGridAngles,
-                                    param.nTotCTFs, algo);
-    handles[g] = h;
+    // an orientation block owns its angle entries: shard handle (table [o1-o0][nMaps] stays on the device, K best
+    // selected there).  With the CTF split an orientation has several owners: plain handles, full (tiny) table,
+    // host merge of the angle entries
+    const int rc = splitCTF ? bioem_hip_create(&h, sh.device, &param.pd, nMaps, nA, nC, algo)
+                            : bioem_hip_create_shard(&h, sh.device, &param.pd, nMaps, nA, nC, algo, sh.o0, sh.o1);
+    sh.h = h;
     check(h, rc, "bioem_hip_create");
     check(h, bioem_hip_upload_particle_maps(h, particles.maps.data()), "upload particles");
     check(h, bioem_hip_upload_ctf(h, param.refCTF.data(), param.ctfParam.data()), "upload CTF");
     check(h, bioem_hip_upload_model(h, model.points.data(), (int) model.points.size(), model.NormDen, param.pixelSize,
                                     param.shiftX, param.shiftY),
           "upload model");
-    check(h, bioem_hip_upload_orientations(h, param.angles.data(), param.nTotGridAngles, param.doquater ? 1 : 0),
-          "upload orientations");
+    check(h, bioem_hip_upload_orientations(h, param.angles.data(), nA, param.doquater ? 1 : 0), "upload orientations");
   }
+  // RCCL carries the merge when every shard has a GPU of its own
+  useRccl = nShards > 1 && nDevUsed == nShards && !splitCTF && !getenv("BIOEM_HOST_MERGE");
   return 0;
 }
 
 int Driver::run()
 {
   printf("\tInitializing Probabilities\n");
-  const int nMaps = particles.ntot, nAngles = param.nTotGridAngles;
-  const size_t bytes = bioem_hip_prob_size(nMaps, nAngles, param.pd.writeAngles);
-  shardProb.assign(nGpus, nullptr);
-  for (int g = 0; g < nGpus; g++)
+  const int nMaps = particles.ntot, nAngles = param.nTotGridAngles, nC = param.nTotCTFs;
+  const int nShards = (int) shards.size();
+  const int K = param.pd.writeAngles;
+  const double numconst = 0.5 * log(M_PI) + (1 - param.pd.Ntotpi * 0.5) * (log(2 * M_PI) + 1) + log(param.pd.volu);
+  // per shard: the host block start_run / finish_run move -- map entries only for orientation-block shards, map
+  // entries + the (tiny) full angle table when the CTF grid is split
+  const size_t bytes = splitCTF ? bioem_hip_prob_size(nMaps, nAngles, K) : bioem_hip_prob_size(nMaps, 0, 0);
+  for (Shard &sh : shards)
   {
     void *p = bioem_hip_host_alloc(bytes); // == bioem::malloc_device_host (map.cpp:637)
     if (!p)
       fatal("Memory allocation");
-    shardProb[g] = p;
+    sh.prob = p;
     bioem_hip_prob_map *pm = (bioem_hip_prob_map *) p;
     for (int i = 0; i < nMaps; i++) // bioem.cpp:681-699
     {
@@ -249,7 +297,7 @@ int Driver::run()
       pm[i].Total = 0.0;
       pm[i].Constoadd = -999999.;
     }
-    if (param.pd.writeAngles)
+    if (K && splitCTF)
     {
       bioem_hip_prob_angle *pa = (bioem_hip_prob_angle *) (pm + nMaps);
       for (size_t e = 0; e < (size_t) nMaps * nAngles; e++)
@@ -260,55 +308,135 @@ int Driver::run()
     }
   }
   if (debugOutput >= 1)
-    printf("\tMain Loop GridAngles %d, CTFs %d, RefMaps %d, Shifts (%d/%d)², Pixels %d², GPUs %d\n", nAngles,
-           param.nTotCTFs, nMaps, 2 * param.pd.maxDisplaceCenter + param.pd.GridSpaceCenter, param.pd.GridSpaceCenter,
-           param.N, nGpus);
+    printf("\tMain Loop GridAngles %d, CTFs %d, RefMaps %d, Shifts (%d/%d)², Pixels %d², Shards %d%s, merge %s\n", nAngles,
+           nC, nMaps, 2 * param.pd.maxDisplaceCenter + param.pd.GridSpaceCenter, param.pd.GridSpaceCenter, param.N,
+           nShards, splitCTF ? " (orientation x CTF split)" : "", useRccl ? "RCCL" : "host");
   std::vector<std::thread> th;
-  std::vector<std::string> errs(nGpus);
-  for (int g = 0; g < nGpus; g++)
+  std::vector<std::string> errs(nShards);
+  for (int g = 0; g < nShards; g++)
   {
     th.emplace_back([&, g]() {
-      bioem_hip_handle h = handles[g];
-      // same contiguous blocks as `mpirun -n nGpus` (bioem.cpp:748-753)
-      const int o0 = (int) ((long long) g * nAngles / nGpus);
-      const int o1 = (int) ((long long) (g + 1) * nAngles / nGpus);
-      if (bioem_hip_start_run(h, shardProb[g]) || bioem_hip_project_convolve_compare(h, o0, o1) ||
-          bioem_hip_finish_run(h, shardProb[g]))
+      Shard &sh = shards[g];
+      bioem_hip_handle h = sh.h;
+      int rc = bioem_hip_start_run(h, sh.prob);
+      if (!rc && !splitCTF)
+        rc = bioem_hip_project_convolve_compare(h, sh.o0, sh.o1);
+      // CTF split: the shard's run of (orientation, CTF) pairs, one rectangle per orientation it touches
+      for (long long u = sh.u0; !rc && splitCTF && u < sh.u1;)
+      {
+        const int o = (int) (u / nC), c0 = (int) (u % nC);
+        const int c1 = (int) std::min<long long>(nC, c0 + (sh.u1 - u));
+        rc = bioem_hip_project_convolve_compare_ctf(h, o, o + 1, c0, c1);
+        u += c1 - c0;
+      }
+      if (!rc)
+        rc = bioem_hip_finish_run(h, sh.prob);
+      if (rc)
         errs[g] = bioem_hip_last_error(h);
     });
   }
   for (auto &t : th)
     t.join();
-  for (int g = 0; g < nGpus; g++)
+  for (int g = 0; g < nShards; g++)
     if (!errs[g].empty())
-      fatal("device %d: %s", g, errs[g].c_str());
-  prob.assign(bytes, 0);
-  if (nGpus == 1)
-    memcpy(prob.data(), shardProb[0], bytes);
-  else if (bioem_hip_merge_host(nGpus, nMaps, nAngles, param.pd.writeAngles, (const void *const *) shardProb.data(),
-                                prob.data()))
-    fatal("merge failed");
+      fatal("shard %d: %s", g, errs[g].c_str());
+
+  // ---- the path's single exchange step: merge of the shards (bioem.cpp:909-1044) ----
+  prob.assign(sizeof(bioem_hip_prob_map) * (size_t) nMaps, 0);
+  cand.assign((size_t) nMaps * K, bioem_hip_angle_candidate());
+  if (useRccl)
+  { // one GPU per shard: all-gather over xGMI, fold on the first device
+    std::vector<bioem_hip_handle> hs;
+    for (Shard &sh : shards)
+      hs.push_back(sh.h);
+    check(hs[0], bioem_hip_merge(hs.data(), nShards, prob.data(), K, numconst, K ? cand.data() : nullptr), "RCCL merge");
+  }
+  else if (!splitCTF)
+  {
+    std::vector<const void *> blocks;
+    for (Shard &sh : shards)
+      blocks.push_back(sh.prob);
+    if (bioem_hip_merge_host(nShards, nMaps, 0, 0, blocks.data(), prob.data()))
+      fatal("merge failed");
+    if (K)
+    {
+      std::vector<std::vector<bioem_hip_angle_candidate>> lists(nShards);
+      std::vector<const bioem_hip_angle_candidate *> ptrs(nShards);
+      for (int g = 0; g < nShards; g++)
+      {
+        lists[g].resize((size_t) nMaps * K);
+        check(shards[g].h, bioem_hip_topk_angles(shards[g].h, K, numconst, lists[g].data()), "top-K orientations");
+        ptrs[g] = lists[g].data();
+      }
+      if (bioem_hip_merge_topk_host(nShards, nMaps, K, ptrs.data(), cand.data()))
+        fatal("merge failed");
+    }
+  }
+  else
+  { // CTF split: an orientation's angle entry is spread over shards -> log-sum-exp merge of the full tables, then the
+    // writer's selection on the host (bioem.cpp:1251-1286)
+    std::vector<unsigned char> full(bytes);
+    std::vector<const void *> blocks;
+    for (Shard &sh : shards)
+      blocks.push_back(sh.prob);
+    if (bioem_hip_merge_host(nShards, nMaps, nAngles, K, blocks.data(), full.data()))
+      fatal("merge failed");
+    memcpy(prob.data(), full.data(), prob.size());
+    if (K)
+    {
+      const bioem_hip_prob_angle *pang = (const bioem_hip_prob_angle *) (full.data() + prob.size());
+      typedef std::pair<double, int> Item;
+      for (int i = 0; i < nMaps; i++)
+      {
+        std::priority_queue<Item, std::vector<Item>, std::greater<Item>> q;
+        for (int io = 0; io < nAngles; io++)
+        {
+          const bioem_hip_prob_angle &pa = pang[(size_t) io * nMaps + i];
+          const double logp = log(pa.forAngles) + pa.ConstAngle + numconst;
+          if ((int) q.size() < K)
+            q.push(Item(logp, io));
+          else if (q.top().first < logp)
+          {
+            q.pop();
+            q.push(Item(logp, io));
+          }
+        }
+        const int cnt = (int) q.size();
+        for (int r = 0; r < K; r++)
+          cand[(size_t) i * K + r].orient = -1;
+        for (int r = cnt - 1; r >= 0; r--)
+        {
+          const bioem_hip_prob_angle &pa = pang[(size_t) q.top().second * nMaps + i];
+          bioem_hip_angle_candidate &c = cand[(size_t) i * K + r];
+          c.forAngles = pa.forAngles;
+          c.ConstAngle = pa.ConstAngle;
+          c.logp = q.top().first;
+          c.orient = q.top().second;
+          q.pop();
+        }
+      }
+    }
+  }
   writeOutput();
   return 0;
 }
 
 void Driver::cleanup()
 {
-  for (void *p : shardProb)
-    bioem_hip_host_free(p);
-  shardProb.clear();
-  for (bioem_hip_handle h : handles)
-    if (h)
-      bioem_hip_destroy(h);
-  handles.clear();
+  for (Shard &sh : shards)
+  {
+    bioem_hip_host_free(sh.prob);
+    if (sh.h)
+      bioem_hip_destroy(sh.h);
+  }
+  shards.clear();
 }
 
 // Output_Probabilities and ANG_PROB, text layout of bioem.cpp:1047-1374 (fixed, 4 decimals).
 void Driver::writeOutput()
 {
-  const int nMaps = particles.ntot, nAngles = param.nTotGridAngles;
+  const int nMaps = particles.ntot;
   const bioem_hip_prob_map *pmap = (const bioem_hip_prob_map *) prob.data();
-  const bioem_hip_prob_angle *pang = (const bioem_hip_prob_angle *) (pmap + nMaps);
   const bioem_hip_param_device &pd = param.pd;
   const double numconst = 0.5 * log(M_PI) + (1 - pd.Ntotpi * 0.5) * (log(2 * M_PI) + 1) + log(pd.volu);
   const char *bar = "************************* HEADER:: NOTATION *******************************************\n";
@@ -390,40 +518,23 @@ void Driver::writeOutput()
     }
     if (pd.writeAngles)
     {
-      // K best orientations through a min-heap on (logp, orientation), best first (bioem.cpp:1251-1286)
-      typedef std::pair<double, int> Item;
-      std::priority_queue<Item, std::vector<Item>, std::greater<Item>> q;
-      const unsigned Kbest = (unsigned) pd.writeAngles;
-      for (int io = 0; io < nAngles; io++)
+      // the K best orientations (selected by the reference's min-heap rule, bioem.cpp:1251-1286 -- on the device for
+      // orientation-block shards, see Driver::run), best first
+      const int Kbest = pd.writeAngles;
+      for (int r = 0; r < Kbest; r++)
       {
-        const bioem_hip_prob_angle &pa = pang[(size_t) io * nMaps + i];
-        const double logp = log(pa.forAngles) + pa.ConstAngle + numconst;
-        if (q.size() < Kbest)
-          q.push(Item(logp, io));
-        else if (q.top().first < logp)
-        {
-          q.pop();
-          q.push(Item(logp, io));
-        }
-      }
-      std::vector<Item> best(q.size());
-      for (int r = (int) q.size() - 1; r >= 0; r--)
-      {
-        best[r] = q.top();
-        q.pop();
-      }
-      for (const Item &it : best)
-      {
-        const int io = it.second;
-        const bioem_hip_prob_angle &pa = pang[(size_t) io * nMaps + i];
-        double logp = it.first;
+        const bioem_hip_angle_candidate &c = cand[(size_t) i * Kbest + r];
+        if (c.orient < 0)
+          break;
+        const int io = c.orient;
+        double logp = c.logp;
         if (param.yespriorAngles)
           logp += param.angprior[io];
         const float *q4 = A + 4 * (size_t) io;
         ang << " " << i << " " << q4[0] << " " << q4[1] << " " << q4[2] << " ";
         if (param.doquater)
           ang << q4[3] << " ";
-        ang << logp << " Separated: " << log(pa.forAngles) << " " << pa.ConstAngle << " " << numconst;
+        ang << logp << " Separated: " << log(c.forAngles) << " " << c.ConstAngle << " " << numconst;
         if (param.yespriorAngles)
           ang << " " << param.angprior[io];
         ang << "\n";

@@ -70,6 +70,18 @@ typedef struct
   float density;
 } bioem_hip_model_point;
 
+/* One of the K most probable orientations of a particle (WRITE_PROB_ANGLES): the angle entry of orientation
+ * `orient` (global index) and logp = log(forAngles) + ConstAngle + numconst, the key the reference's writer ranks
+ * by (/root/reference/bioem.cpp:1251-1286).  32 bytes. */
+typedef struct
+{
+  double forAngles;
+  double ConstAngle;
+  double logp;
+  int orient;
+  int pad;
+} bioem_hip_angle_candidate;
+
 typedef struct bioem_hip_ctx *bioem_hip_handle;
 
 /* Number of visible HIP devices (replaces bioem_cuda::selectCudaDevice, bioem_cuda.cu:686-816). */
@@ -80,6 +92,14 @@ int bioem_hip_device_count(void);
  * semantics of bioem_algorithm.h:144-198 / bioem.cpp:1461-1602).  device = HIP ordinal. */
 int bioem_hip_create(bioem_hip_handle *out, int device, const bioem_hip_param_device *pd, int nMaps, int nAngles,
                      int nCTF, int algo);
+/* Shard variant of bioem_hip_create for orientation-sharded runs (the reference's MPI blocks, bioem.cpp:748-753): this
+ * handle only ever compares orientations [iOrientBegin, iOrientEnd) of the nAngles global ones.  With
+ * WRITE_PROB_ANGLES its angle table is [iOrientEnd - iOrientBegin][nMaps] (each orientation has one owner) and stays on
+ * the device: start_run / finish_run move only the nMaps 40-byte map entries (bioem_hip_prob_size(nMaps, 0, 0)
+ * bytes), the K best orientations per particle come from bioem_hip_topk_angles.  Orientation and CTF indices in all
+ * calls and results stay GLOBAL. */
+int bioem_hip_create_shard(bioem_hip_handle *out, int device, const bioem_hip_param_device *pd, int nMaps, int nAngles,
+                           int nCTF, int algo, int iOrientBegin, int iOrientEnd);
 int bioem_hip_destroy(bioem_hip_handle h); /* bioem_cuda::deviceExit, bioem_cuda.cu:1023-1053 */
 const char *bioem_hip_last_error(bioem_hip_handle h);
 
@@ -123,13 +143,38 @@ int bioem_hip_compare(bioem_hip_handle h, int iPipeline, int iOrient, int iConvS
  * entirely on the device. */
 int bioem_hip_project_convolve_compare(bioem_hip_handle h, int iOrientBegin, int iOrientEnd);
 
+/* The same for orientations [iOrientBegin, iOrientEnd) and CTFs [iConvBegin, iConvEnd) only: when there are fewer
+ * orientations than GPUs the CTF grid is split as well (north_star: "orientations x CTF-envelope grid shard"). */
+int bioem_hip_project_convolve_compare_ctf(bioem_hip_handle h, int iOrientBegin, int iOrientEnd, int iConvBegin,
+                                           int iConvEnd);
+
 /* bioem_cuda::deviceFinishRun (bioem_cuda.cu:1013-1021): synchronise, download the probability block. */
 int bioem_hip_finish_run(bioem_hip_handle h, void *pProb_host);
+
+/* WRITE_PROB_ANGLES without moving the table: selects on the device the K best orientations of every particle among
+ * the orientations this handle owns, with the reference writer's own rule (a K-entry min-heap on (logp, orientation)
+ * walked in orientation order, bioem.cpp:1251-1286; numconst as computed at bioem.cpp:1141-1150).  out = [nMaps][K],
+ * best first; entries beyond the owned orientation count have orient = -1.  Call after finish_run. */
+int bioem_hip_topk_angles(bioem_hip_handle h, int K, double numconst, bioem_hip_angle_candidate *out);
+/* K-way merge of the shards' candidate lists (shards in ascending orientation-block order): the K best of the union,
+ * same heap rule.  cands[s] = [nMaps][K]; out = [nMaps][K], best first. */
+int bioem_hip_merge_topk_host(int nShards, int nMaps, int K, const bioem_hip_angle_candidate *const *cands,
+                              bioem_hip_angle_candidate *out);
 
 /* Log-sum-exp merge of orientation shards (replaces the MPI merge of bioem.cpp:909-1044) on the host:
  * shards = nShards probability blocks of identical shape, out = merged block.  Ties on Constoadd go to
  * the lowest shard (= lowest orientation index, the serial semantics). */
 int bioem_hip_merge_host(int nShards, int nMaps, int nAngles, int writeAngles, const void *const *shards, void *out);
+
+/* The path's single exchange step over RCCL / xGMI (replaces the MPI merge of bioem.cpp:909-1044) for n handles on n
+ * DIFFERENT GPUs of this process: every device contributes its nMaps map entries -- and, when K > 0, its K best
+ * orientations per particle (bioem_hip_topk_angles) -- to ONE ncclAllGather; the device of handles[0] folds the
+ * gathered shards (log-sum-exp of Total / Constoadd, arg-max record from the lowest shard holding the maximum =
+ * lowest orientation index; candidates by the heap rule) and the result is copied to the host.
+ * pProbMaps_host = [nMaps] bioem_hip_prob_map, cand_host = [nMaps][K] or NULL when K == 0.  Call after every handle's
+ * finish_run.  The communicator is created on first use (ncclCommInitAll) and cached; librccl.so is loaded lazily. */
+int bioem_hip_merge(bioem_hip_handle *handles, int n, void *pProbMaps_host, int K, double numconst,
+                    bioem_hip_angle_candidate *cand_host);
 
 /* Stand-alone forward transform (FFTW r2c convention, [N][N/2+1] (re,im)) of nImg real N x N images on
  * `device`; replaces the fftwf_execute_dft_r2c call of the PSF kernel set-up (param.cpp:1521). */

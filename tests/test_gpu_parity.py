@@ -218,6 +218,124 @@ def test_write_prob_angles():
         E.close()
 
 
+def make_shard_engine(S, algo, o0, o1):
+    import bioem_amd.engine as eng
+    E = eng.Engine(pd_of(S), S.nMaps, S.nAngles, S.nCTF, algo=algo, device=0, shard=(o0, o1))
+    E.upload_particles(S.refFFT, S.sumRef, S.sumsqRef)
+    E.upload_ctf(S.refCTF, S.ctfParam)
+    E.upload_model(S.points, S.NormDen, S.px, S.P["shiftX"], S.P["shiftY"])
+    E.upload_orientations(S.angles, S.isQuat)
+    return E
+
+
+def run_shard(E, o0, o1):
+    import bioem_amd.engine as eng
+    raw, pmap, _ = eng.new_prob_block(E.nMaps, 0, 0)        # shard handles move the map entries only
+    E.start_run(raw)
+    E.project_convolve_compare(o0, o1)
+    E.finish_run(raw)
+    return raw, pmap
+
+
+@pytest.mark.parametrize("name,nsh", [("g4_n32_angles", 1), ("g4_n32_angles", 3), ("g11_n32_eulerlist", 2),
+                                      ("g11_n32_eulerlist", 14)])
+def test_sharded_angle_table_and_device_top_k(name, nsh):
+    """WRITE_PROB_ANGLES without moving the table: every shard handle keeps the angle entries of ITS orientation block
+    on the device ([o1-o0][nMaps] instead of [nAngles][nMaps]), selects its K best orientations per particle there
+    (the writer's min-heap rule, bioem.cpp:1251-1286) and the K-way candidate merge must reproduce the K best of the
+    unsharded table: the oracle's rows and the reference's ANG_PROB file (g4, g11 incl. one shard per orientation,
+    where every shard owns fewer orientations than K)."""
+    import bioem_amd.engine as eng
+    case, S = setup_for(name)
+    K = S.pd.writeAngles
+    numconst = orc.logp_constant(S.pd)
+    for algo in case["algos"]:
+        blocks, lists = [], []
+        for g in range(nsh):
+            o0, o1 = g * S.nAngles // nsh, (g + 1) * S.nAngles // nsh
+            E = make_shard_engine(S, algo, o0, o1)
+            raw, _ = run_shard(E, o0, o1)
+            blocks.append(raw.copy())
+            c = E.topk_angles(K, numconst)
+            assert c.shape == (S.nMaps, K)
+            owned = ((c["orient"] >= o0) & (c["orient"] < o1)) | (c["orient"] == -1)
+            assert owned.all() and (c["orient"] >= 0).sum(axis=1).min() == min(K, o1 - o0)
+            if nsh > 1:
+                with pytest.raises(RuntimeError, match="outside the range"):
+                    E.project_convolve_compare(0, S.nAngles)
+            lists.append(c)
+            E.close()
+        merged = eng.merge_host(blocks, S.nMaps, 0, 0).view(eng.PROB_MAP_DTYPE)
+        cand = eng.merge_topk_host(lists)
+        wm, wa = S.run(algo)
+        assert_same_posterior(S, merged, wm)
+        rows = orc.ang_prob_rows(S, wm, wa)
+        gold = iof.parse_ang_prob(os.path.join(case["dir"], "ANG_PROB_algo%d" % algo))
+        pri = S.P.get("angprior")
+        for m in range(S.nMaps):
+            assert [r["orient"] for r in rows[m]] == [int(v) for v in cand[m]["orient"]]
+            for g, r, c in zip(gold[m], rows[m], cand[m]):
+                lp = c["logp"] + (float(pri[c["orient"]]) if pri is not None else 0.0)
+                assert abs(lp - r["logp"]) <= 5e-3 and abs(lp - g["logp"]) <= 5e-3
+                assert abs(np.log(c["forAngles"]) - g["sep"][0]) <= 5e-3 and abs(c["ConstAngle"] - g["sep"][1]) <= 5e-3
+                assert g["angles"] == [float("%.4f" % v) for v in S.angles[c["orient"]][:len(g["angles"])]]
+
+
+def test_rccl_merge_single_rank_communicator():
+    """bioem_hip_merge: the shard merge behind the C ABI over RCCL (ncclCommInitAll + one ncclAllGather, fold on the
+    device).  The box has one GPU, so the communicator has one rank: RCCL initialises, the collective runs on the
+    engine's stream, the folded block and the K best orientations come back -- equal to what finish_run / topk_angles
+    deliver.  Two handles on one device are refused (one GPU per shard)."""
+    import bioem_amd.engine as eng
+    case, S = setup_for("g4_n32_angles")
+    K = S.pd.writeAngles
+    numconst = orc.logp_constant(S.pd)
+    E = make_shard_engine(S, 1, 0, S.nAngles)
+    _, pmap = run_shard(E, 0, S.nAngles)
+    want_c = E.topk_angles(K, numconst)
+    got, got_c = eng.merge_rccl([E], K, numconst)
+    assert got.tobytes() == pmap.tobytes()
+    assert got_c.tobytes() == want_c.tobytes()
+    got2, none = eng.merge_rccl([E])                       # maps only, cached communicator
+    assert none is None and got2.tobytes() == pmap.tobytes()
+    E2 = make_shard_engine(S, 1, 0, S.nAngles)
+    with pytest.raises(RuntimeError, match="one GPU per shard"):
+        eng.merge_rccl([E, E2])
+    E.close()
+    E2.close()
+
+
+def test_ctf_range_entry_and_split_merge():
+    """bioem_hip_project_convolve_compare_ctf: the CTF grid split (used when there are fewer orientations than GPUs).
+    Pieces (orientation block x CTF range) with private blocks, merged in serial visiting order == one run, map entries
+    and angle table."""
+    import bioem_amd.engine as eng
+    case, S = setup_for("g4_n32_angles")
+    E = make_engine(S, 1)
+    _, full, fang = run_native(E, S)
+    blocks = []
+    cuts = [0, 1, 3, S.nCTF]
+    for o0, o1 in ((0, 5), (5, S.nAngles)):
+        for c0, c1 in zip(cuts[:-1], cuts[1:]):
+            raw, _, _ = eng.new_prob_block(S.nMaps, S.nAngles, S.pd.writeAngles)
+            E.start_run(raw)
+            E.project_convolve_compare_ctf(o0, o1, c0, c1)
+            E.finish_run(raw)
+            blocks.append(raw.copy())
+    merged = eng.merge_host(blocks, S.nMaps, S.nAngles, S.pd.writeAngles)
+    mm = merged[:S.nMaps * 40].view(eng.PROB_MAP_DTYPE)
+    ma = merged[S.nMaps * 40:].view(eng.PROB_ANGLE_DTYPE).reshape(S.nAngles, S.nMaps)
+    for a, b in zip(mm, full):
+        assert abs(S.final_logp(a) - S.final_logp(b)) <= 1e-9 * abs(S.final_logp(b))
+        assert (a["orient"], a["conv"], a["cent_x"], a["cent_y"]) == (b["orient"], b["conv"], b["cent_x"], b["cent_y"])
+    la = np.log(ma["forAngles"]) + ma["ConstAngle"]
+    lb = np.log(fang["forAngles"]) + fang["ConstAngle"]
+    assert np.abs(la - lb).max() <= 1e-9 * np.abs(lb).max()
+    with pytest.raises(RuntimeError, match="range invalid"):
+        E.project_convolve_compare_ctf(0, 1, 2, 2)
+    E.close()
+
+
 def test_orientation_shards_merge_to_unsharded_result():
     """(e) multi-GPU semantics on one GPU: k orientation blocks with private probability blocks, merged by the
     log-sum-exp rule == single run."""
@@ -286,8 +404,10 @@ CLI_CASES = ["g10_n64", "g9_n35_odd", "g4_n32_angles", "g5_n32_psf", "g11_n32_eu
 
 # (case, orientation shards): BIOEM_SHARDS > 1 runs the CLI's multi-GPU control flow (one engine context and host
 # thread per shard, private probability blocks, host log-sum-exp merge) with all shards on the one GPU of the box
+# shards > orientations: the (orientation, CTF) pairs are split instead (g3: 4 x 2, g11: 14 x 4 with WRITE_PROB_ANGLES)
 CLI_RUNS = [(c, 1) for c in CLI_CASES] + [("g10_n64", 3), ("g4_n32_angles", 2), ("g11_n32_eulerlist", 5),
-                                          ("g2_n128", 4)]
+                                          ("g2_n128", 4), ("g3_n32_trace", 6), ("g11_n32_eulerlist", 20),
+                                          ("g4_n32_angles", 24)]
 
 
 @pytest.mark.parametrize("name,shards", CLI_RUNS)
@@ -330,6 +450,33 @@ def test_cli_end_to_end_against_reference_outputs(name, shards, tmp_path):
                 for g, m in zip(ga[m_], ma[m_]):
                     assert g["angles"] == m["angles"] and abs(g["logp"] - m["logp"]) <= 5e-3
                     assert len(g["sep"]) == len(m["sep"])
+
+
+def test_cli_accepts_the_reference_performance_knobs(tmp_path):
+    """A job script written for the reference may set its CPU/GPU balancing and CUDA tuning knobs
+    (bioem.cpp:99-135, bioem_cuda.cu:216-222): they are read, reported as having no effect, and change nothing."""
+    exe = os.path.join(ROOT, "bioem_amd", "bin", "bioEM")
+    case, S = setup_for("g10_n64")
+    cmd = [exe, "--Inputfile", os.path.join(case["dir"], "param.txt"), "--OutputFile", "out.txt"] + \
+        write_case_inputs(case, tmp_path)
+    knobs = {"GPU": "1", "GPUWORKLOAD": "60", "GPUASYNC": "0", "GPUDUALSTREAM": "0", "BIOEM_CUDA_THREAD_COUNT": "128",
+             "BIOEM_PROJ_CONV_AT_ONCE": "4", "OMP_NUM_THREADS": "7"}
+    r = subprocess.run(cmd, cwd=str(tmp_path), env=dict(os.environ, BIOEM_GPUS="1", **knobs), stdout=subprocess.PIPE,
+                       stderr=subprocess.STDOUT, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:]
+    for k, v in knobs.items():
+        if k != "GPU":
+            assert "Note - %s=%s accepted, no effect" % (k, v) in r.stdout
+    with_knobs = open(tmp_path / "out.txt").read()
+    r = subprocess.run(cmd, cwd=str(tmp_path), env=dict(os.environ, BIOEM_GPUS="1", GPU="0"), stdout=subprocess.PIPE,
+                       stderr=subprocess.STDOUT, text=True, timeout=300)
+    assert r.returncode == 0 and "GPU=0 accepted, no effect" in r.stdout
+    assert open(tmp_path / "out.txt").read() == with_knobs
+    gold = iof.parse_output_probabilities(golden_output(case, 1))
+    mine = iof.parse_output_probabilities(with_knobs)
+    for g, m in zip(gold, mine):
+        assert abs(g["logp"] - m["logp"]) <= max(ABS_TOL, REL_TOL * abs(g["logp"]))
+        assert (g["angles"], g["ctf"], g["cx"], g["cy"]) == (m["angles"], m["ctf"], m["cx"], m["cy"])
 
 
 def test_cli_error_behaviour(tmp_path):
