@@ -5,54 +5,35 @@ One "step" = one pass of the hot path (projection -> CTF convolution -> FFT cros
 +-10 px displacement window -> log-sum-exp posterior) over this rank's orientation block against all
 particles, followed by the shard merge.  Workload at N GPUs (weak scaling, config 2 per GPU):
   224^2 maps, 1 000 synthetic particles (replicated), 4 608 orientations PER GPU, 5 CTF envelopes,
-  441 displacements; rank r owns orientation block r (the reference's MPI sharding, bioem.cpp:748-753),
-  log-sum-exp merge of the per-particle posteriors by RCCL all-reduce (max, then sum).
+  441 displacements; rank r owns orientation block r of the global list (the reference's MPI sharding,
+  bioem.cpp:748-753); the merge of the per-particle posteriors is ONE all-gather over RCCL + a local fold.
 
-Prints ONE JSON line (rank 0).  `roofline` is measured live with HIP events recorded on the engine's
-stream around every comparison-kernel launch inside the timed region.  `cpu_baseline` (rank 0, N=1)
-times the CPU oracle port on a bounded sample of the same workload.
+Launch: `python bench.py --gpus N` starts N ranks itself when no launcher set WORLD_SIZE (the parent makes no GPU call
+and only forwards rank 0's line); under `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N` the
+ranks come from the launcher.
+
+Prints ONE JSON line (rank 0).  `roofline` names the resource that bounds the comparison kernel -- VALU issue -- and is
+measured live: HIP events recorded on the engine's stream around every comparison-kernel launch of the timed region
+give the launch duration; the wave-instructions per comparison of exactly this kernel instantiation come from the
+committed rocprofv3 counter passes (profiles/pmc_current.json, scripts/profile_round.sh + pmc_summary.py), refused when
+kernel or shape differ.  `hbm` holds the memory side: the north-star's algorithmic bytes, the compulsory bytes and the
+counter-measured fabric traffic.  `cpu_baseline` (rank 0, N=1) times the CPU oracle port on a bounded sample.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
-
-import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+HBM_PEAK_GBS = 8000.0               # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+VALU_PEAK_GINSTR = 1024 * 2.4 / 2   # 256 CUs x 4 SIMDs, one wave64 VALU instruction per 2 cycles at 2.4 GHz (same guide)
 
 
-def cpu_baseline(W, n_orient, n_threads):
-    """CPU oracle port (oracle/bioem_oracle.c: full c2r FFT cross-correlation + calProb loop, OpenMP over
-    particles like bioem.cpp:1392) on `n_orient` orientations x all CTFs x all particles of this workload."""
-    import ctypes as C
-    import oracle as orc
-    L = orc.lib()
-    L.orc_set_num_threads(n_threads)
-    N, H = W.N, W.N // 2 + 1
-    nP = W.nP
-    pd = orc.ParamDevice()
-    for f, _ in orc.ParamDevice._fields_:
-        setattr(pd, f, getattr(W.pd, f))
-    refFFT, sumRef, sumsqRef = W.engine.debug_particles()
-    pts = np.zeros(len(W.points), dtype=orc.POINT_DTYPE)
-    for k in ("pos", "radius", "density"):
-        pts[k] = W.points[k]
-    pmap = np.zeros(nP, dtype=orc.PROB_MAP_DTYPE)
-    L.orc_init_prob(nP, W.nOrient, 0, pmap.ctypes.data, None)
-    t0 = time.time()
-    L.orc_run(C.byref(pd), 1, pts.ctypes.data, len(pts), W.NormDen, W.angles.ctypes.data, W.nOrient, 1, W.px, 0, 0,
-              W.nCTF, W.refCTF.ctypes.data, W.ctfParam.ctypes.data, nP, refFFT.ctypes.data, sumRef.ctypes.data,
-              sumsqRef.ctypes.data, 0, n_orient, pmap.ctypes.data, None)
-    dt = time.time() - t0
-    return n_orient * W.nCTF * nP / dt, dt, pmap, orc.logp_constant(pd)
-
-
-def main():
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
@@ -64,11 +45,84 @@ def main():
     ap.add_argument("--defocus", type=int, default=1, help="CTF_DEFOCUS grid points (config 3: 2 x 5 envelopes = 10 CTFs)")
     ap.add_argument("--max-displacement", type=int, default=10, help="DISPLACE_CENTER half width (pixels)")
     ap.add_argument("--grid", type=int, default=1, help="DISPLACE_CENTER grid spacing")
-    ap.add_argument("--write-angles", action="store_true", help="WRITE_PROB_ANGLES: keep the per-orientation table")
+    ap.add_argument("--write-angles", type=int, nargs="?", const=10, default=0, metavar="K",
+                    help="WRITE_PROB_ANGLES K: keep the per-orientation table (on the device, sharded) and select the K "
+                         "best orientations per particle")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-orientations", type=int, default=64, help="orientations of the CPU-baseline sample (~12 s)")
-    args = ap.parse_args()
+    ap.add_argument("--cpu-orientations", type=int, default=64, help="orientations of the CPU-baseline sample")
+    ap.add_argument("--cpu-repeats", type=int, default=3)
+    return ap.parse_args()
 
+
+def self_launch(args):
+    """No launcher in the environment: start the N ranks as fresh child processes (this parent never touches the GPU;
+    nothing is exec'ed from a GPU-initialised process) and hand rank 0's output through."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out, _ = procs[0].communicate()
+    rc = procs[0].returncode
+    for p in procs[1:]:
+        rc = p.wait() or rc
+    sys.stdout.write(out.decode())
+    sys.stdout.flush()
+    sys.exit(rc)
+
+
+def cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for ln in f:
+                if ln.startswith("model name"):
+                    return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(W, n_orient, n_threads, repeats):
+    """CPU oracle port (oracle/bioem_oracle.c: full c2r FFT cross-correlation + calProb loop, OpenMP over
+    particles like bioem.cpp:1392) on `n_orient` orientations x all CTFs x all particles of this workload;
+    median of `repeats` runs."""
+    import ctypes as C
+    import numpy as np
+    import oracle as orc
+    L = orc.lib()
+    L.orc_set_num_threads(n_threads)
+    nP = W.nP
+    pd = orc.ParamDevice()
+    for f, _ in orc.ParamDevice._fields_:
+        setattr(pd, f, getattr(W.pd, f))
+    refFFT, sumRef, sumsqRef = W.engine.debug_particles()
+    pts = np.zeros(len(W.points), dtype=orc.POINT_DTYPE)
+    for k in ("pos", "radius", "density"):
+        pts[k] = W.points[k]
+    times = []
+    for _ in range(repeats):
+        pmap = np.zeros(nP, dtype=orc.PROB_MAP_DTYPE)
+        L.orc_init_prob(nP, len(W.angles), 0, pmap.ctypes.data, None)
+        t0 = time.time()
+        L.orc_run(C.byref(pd), 1, pts.ctypes.data, len(pts), W.NormDen, W.angles.ctypes.data, len(W.angles), 1, W.px, 0,
+                  0, W.nCTF, W.refCTF.ctypes.data, W.ctfParam.ctypes.data, nP, refFFT.ctypes.data, sumRef.ctypes.data,
+                  sumsqRef.ctypes.data, 0, n_orient, pmap.ctypes.data, None)
+        times.append(time.time() - t0)
+    dt = sorted(times)[len(times) // 2]
+    return n_orient * W.nCTF * nP / dt, times, pmap, orc.logp_constant(pd)
+
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args)
+    import numpy as np
     import torch
     import torch.distributed as dist
 
@@ -99,23 +153,31 @@ def main():
     from bioem_amd.engine import new_prob_block
     from bioem_amd.synthetic import Workload
 
-    # every rank renders the same particle stack (same seeds); orientation seed differs per rank so that the
-    # global list is the concatenation of `world` distinct blocks of `orientations` each.
-    W = Workload(N=args.pixels, nP=args.particles, nOrient=args.orientations, device=gpu_index,
-                 orient_seed=20260103 + rank, nEnv=args.envelopes, nDefocus=args.defocus, maxD=args.max_displacement, grid=args.grid,
-                 write_angles=args.write_angles)
+    # the global orientation list is `world` blocks of `orientations`; rank r owns block r; every rank renders the
+    # same particle stack (from block 0, same seeds), i.e. the N = 1 workload's stack
+    K = int(args.write_angles)
+    W = Workload(N=args.pixels, nP=args.particles, nOrient=args.orientations, device=gpu_index, nEnv=args.envelopes,
+                 nDefocus=args.defocus, maxD=args.max_displacement, grid=args.grid, write_angles=K, blocks=world,
+                 block=rank)
     E = W.engine
     nMaps = W.nP
+    numconst = 0.0
+    if K:
+        import math
+        numconst = 0.5 * math.log(math.pi) + (1 - float(W.pd.Ntotpi) * 0.5) * (math.log(2 * math.pi) + 1) + math.log(
+            float(W.pd.volu))
+    shard_engine = E.shard is not None
 
     def one_step():
-        raw, pmap, _ = new_prob_block(nMaps, W.nOrient, int(args.write_angles))
+        raw, pmap, _ = new_prob_block(nMaps, 0 if shard_engine else W.nOrient, 0)
         E.start_run(raw)
-        E.project_convolve_compare(0, W.nOrient)
+        E.project_convolve_compare(W.o0, W.o1)
         E.finish_run(raw)
+        cands = E.topk_angles(K, numconst) if K else None      # K x nMaps x 32 B instead of the table
         if world > 1:
-            # the path's single exchange step: log-sum-exp merge of bioem.cpp:909-994 over RCCL
-            return merge_prob_maps(pmap, dev)
-        return pmap
+            # the path's single exchange step (reference: MPI merge, bioem.cpp:909-1044): one all-gather + fold
+            return merge_prob_maps(pmap, dev, cands=cands)
+        return (pmap, cands) if K else pmap
 
     def sync():
         if world > 1:
@@ -128,7 +190,7 @@ def main():
     E.reset_kernel_stats()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        one_step()
+        last = one_step()
     sync()
     dt = time.perf_counter() - t0
     kms, launches, ncomp = E.kernel_stats()
@@ -151,7 +213,9 @@ def main():
     total_comparisons = world * W.comparisons_per_pass * args.steps
     value = total_comparisons / dt
     b_alg = 8 * W.N * (W.N // 2 + 1)  # bytes: one read of the particle half-spectrum per comparison
-    achieved = (ncomp * b_alg / 1e9) / (kms / 1e3) if kms > 0 else 0.0
+    avg_ms = (kms / launches) if launches else None
+    cpl = (ncomp / launches) if launches else None
+    sig = E.kernel_signature
 
     out = {
         "metric": metric_name,
@@ -167,41 +231,80 @@ def main():
         "dtype": "f32",
         "data": "synthetic",
         "config": {"workload": "%s: %d^2 maps, %d particles, %d orientations/GPU, %d CTFs, +-%d px grid %d (%d "
-                               "displacements)" % (workload_name, W.N, W.nP, W.nOrient, W.nCTF,
-                                                   args.max_displacement, args.grid, int(W.pd.NtotDisp)),
+                               "displacements)%s" % (workload_name, W.N, W.nP, W.nOrient, W.nCTF,
+                                                      args.max_displacement, args.grid, int(W.pd.NtotDisp),
+                                                      (", WRITE_PROB_ANGLES %d" % K) if K else ""),
                    "pixels": W.N, "particles": W.nP, "orientations_per_gpu": W.nOrient, "ctf": W.nCTF,
                    "displacements": int(W.pd.NtotDisp), "orientation_list": "seeded uniform random quaternions",
-                   "fast_path": bool(E.fast_path), "parallelism": "orientation blocks x%d, RCCL log-sum-exp merge"
-                   % world},
-        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                     "kernel": E.kernel_name, "launches": int(launches),
-                     "avg_launch_ms": (kms / launches) if launches else None,
-                     "alg_bytes_per_comparison": b_alg,
-                     "comparisons_per_launch": (ncomp / launches) if launches else None},
+                   "fast_path": bool(E.fast_path), "parallelism": "orientation blocks x%d, one RCCL all-gather + "
+                   "log-sum-exp fold" % world},
     }
-    # HBM traffic of the same kernel on the same per-launch workload from the committed rocprofv3 PMC passes
-    # (profiles/pmc_traffic.json, collected in separate --pmc runs; cannot be sampled inside this process)
+    # ---- roofline of the dominant kernel: VALU issue (the kernel is instruction-issue bound, not HBM bound) ----
+    rl = {"bound": "valu_issue", "achieved": None, "peak": VALU_PEAK_GINSTR, "unit": "G wave-instr/s", "frac": None,
+          "traffic": None, "kernel": sig, "launches": int(launches), "avg_launch_ms": avg_ms,
+          "comparisons_per_launch": cpl,
+          "peak_definition": "1024 SIMDs x 2.4 GHz / 2 cycles per wave64 VALU instruction (MI355X_MICROARCH.md)"}
+    hbm = {"peak_GBps": HBM_PEAK_GBS, "alg_bytes_per_comparison": b_alg,
+           "alg_GBps": (ncomp * b_alg / 1e9) / (kms / 1e3) if kms > 0 else None,
+           "alg_note": "north-star model (one particle half-spectrum per comparison); L1/L2 reuse makes it exceed the "
+                       "real traffic, it is not a fraction of anything",
+           "compulsory_bytes_per_launch": (W.nP + cpl / W.nP) * b_alg if cpl else None,
+           "counter_bytes_per_launch": None, "counter_GBps": None, "frac_of_peak": None}
     try:
-        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+        with open(os.path.join(ROOT, "profiles", "pmc_current.json")) as f:
             pmc = json.load(f)
-        if launches and abs(ncomp / launches - pmc["comparisons_per_launch"]) < 1 and W.N == 224:
-            out["roofline"]["traffic"] = pmc["traffic_bytes_per_launch"] / 1e9 / (kms / launches / 1e3)
-            out["roofline"]["traffic_bytes_per_launch"] = pmc["traffic_bytes_per_launch"]
-            out["roofline"]["traffic_source"] = "profiles/%s_pmc_summary.json" % pmc["tag"]
-    except (OSError, KeyError, ValueError):
-        pass
+        same = (pmc.get("kernel") and sig.replace(" ", "") in pmc["kernel"].replace(" ", "") and cpl and
+                abs(cpl - pmc["comparisons_per_launch"]) < 1 and pmc["config"]["pixels"] == W.N and
+                pmc["config"]["particles"] == W.nP and pmc["config"]["ctf"] == W.nCTF and
+                pmc["config"]["displacements"] == int(W.pd.NtotDisp))
+        if same and avg_ms:
+            d = pmc["derived"]
+            ipc = d["valu_wave_instr_per_comparison"]
+            rl["valu_wave_instr_per_comparison"] = ipc
+            rl["achieved"] = ipc * cpl / (avg_ms / 1e3) / 1e9
+            rl["frac"] = rl["achieved"] / VALU_PEAK_GINSTR
+            rl["clock_mhz_under_pmc"] = d.get("clock_mhz_under_pmc")
+            rl["frac_at_sustained_clock"] = d.get("valu_issue_frac_at_sustained_clock")
+            rl["counters_source"] = "profiles/%s_pmc_summary.json (same kernel instantiation and launch shape)" % pmc["tag"]
+            rl["traffic"] = d.get("traffic_bytes_per_launch")
+            hbm["counter_bytes_per_launch"] = d.get("traffic_bytes_per_launch")
+            if d.get("traffic_bytes_per_launch"):
+                hbm["counter_GBps"] = d["traffic_bytes_per_launch"] / (avg_ms / 1e3) / 1e9
+                hbm["frac_of_peak"] = hbm["counter_GBps"] / HBM_PEAK_GBS
+            hbm["l2_hit_rate"] = d.get("l2_hit_rate")
+        else:
+            rl["counters_source"] = "none: profiles/pmc_current.json is for another kernel or launch shape"
+    except (OSError, KeyError, ValueError, TypeError):
+        rl["counters_source"] = "none: profiles/pmc_current.json missing"
+    out["roofline"] = rl
+    out["hbm"] = hbm
+
+    if world > 1 and rank == 0:
+        # the merged block, checked: arg-max orientations are global indices, and the planted truth (particle p was
+        # rendered from orientation (7919 p) mod orientations of block 0) is what most particles must select
+        merged = last[0] if K else last
+        planted = (7919 * np.arange(nMaps)) % W.nOrient
+        out["merge_check"] = {"orient_in_range": bool(((merged["orient"] >= 0) & (merged["orient"] < world * W.nOrient)).all()),
+                              "planted_orientation_recovered": float((merged["orient"] == planted).mean()),
+                              "finite": bool(np.isfinite(merged["Constoadd"]).all() and (merged["Total"] > 0).all())}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         sys.path.insert(0, os.path.join(ROOT, "oracle"))
         import oracle as orc
-        nthreads = orc.usable_cpus(cap=16)  # the GPU box's CPU share for one GPU
+        # every host core this process may use: affinity mask, cut to the cgroup's CPU quota if there is one; on a box
+        # where neither tells the share (all 256 host cores visible, quota unlimited) BIOEM_CPU_THREADS sets it
+        nthreads = orc.usable_cpus(cap=int(os.environ.get("BIOEM_CPU_THREADS", 1 << 20)))
         nco = min(args.cpu_orientations, W.nOrient)
-        v, secs, want, const = cpu_baseline(W, nco, nthreads)
+        v, times, want, const = cpu_baseline(W, nco, nthreads, max(1, args.cpu_repeats))
+        import ctypes.util
         out["cpu_baseline"] = {"value": v, "unit": "comparisons/s", "cores": nthreads, "kind": "port",
-                               "sample": "%d orientations x %d CTF x %d particles of the same workload (%.1f s)"
-                               % (nco, W.nCTF, W.nP, secs)}
+                               "cpu_model": cpu_model(), "host_cores_total": os.cpu_count(),
+                               "cgroup_cpu_limit": orc.cgroup_cpu_limit(),
+                               "repeat_seconds": [round(t, 2) for t in times], "statistic": "median of repeats",
+                               "fftw3f_on_box": bool(ctypes.util.find_library("fftw3f")),
+                               "sample": "%d orientations x %d CTF x %d particles of the same workload, %d repeats"
+                               % (nco, W.nCTF, W.nP, len(times))}
         # the checker's second job: the HIP path on the SAME sample against the oracle (untimed)
-        raw, got, _ = new_prob_block(nMaps, W.nOrient, int(args.write_angles))
+        raw, got, _ = new_prob_block(nMaps, 0 if shard_engine else W.nOrient, 0)
         E.start_run(raw)
         E.project_convolve_compare(0, nco)
         E.finish_run(raw)

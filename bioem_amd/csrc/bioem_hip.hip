@@ -1782,6 +1782,25 @@ const char *bioem_hip_kernel_name(bioem_hip_handle h)
   return h->rowsK ? (h->oddR ? "k_compare_oddfft" : "k_compare_rows") : "k_compare_generic";
 }
 
+const char *bioem_hip_kernel_signature(bioem_hip_handle h)
+{
+  if (!h)
+    return "";
+  static thread_local char buf[96];
+  const char *nq = h->nyq ? "true" : "false";
+  if (h->fast && h->tileT && h->wideWPC)
+    snprintf(buf, sizeof(buf), "k_compare_wide<%d, %d, %d, %s>", 2 * h->fast, h->gs, h->wideWPC, nq);
+  else if (h->fast)
+    snprintf(buf, sizeof(buf), "k_compare_fast<%d, %d, %s, %d>", h->winD, 2 * h->fast, nq, h->gs);
+  else if (h->rowsK && h->oddR)
+    snprintf(buf, sizeof(buf), "k_compare_oddfft<%d, %d>", h->winD, h->oddR);
+  else if (h->rowsK)
+    snprintf(buf, sizeof(buf), "k_compare_rows<%d, %d>", h->winD, h->gs);
+  else
+    snprintf(buf, sizeof(buf), "k_compare_generic");
+  return buf;
+}
+
 int bioem_hip_r2c(int device, int N, int nImg, const float *in, float *out)
 {
   if (N < 1 || N > kMaxPixels || nImg < 1 || hipSetDevice(device) != hipSuccess || dft_allow_lds(N) != hipSuccess)

@@ -197,6 +197,10 @@ int bioem_hip_uses_fast_path(bioem_hip_handle h);
 /* name of the comparison kernel this configuration runs: "k_compare_fast", "k_compare_wide" (tiled wide window),
  * "k_compare_oddfft" / "k_compare_rows" (odd image size with / without a factor 3 or 5) or "k_compare_generic" */
 const char *bioem_hip_kernel_name(bioem_hip_handle h);
+/* the same with the template arguments of the instantiation, spelled as rocprofv3 prints them (e.g.
+ * "k_compare_fast<10, 32, false, 1>"): lets bench.py tie its live timing to the committed counter profile of exactly
+ * this kernel */
+const char *bioem_hip_kernel_signature(bioem_hip_handle h);
 int bioem_hip_synchronize(bioem_hip_handle h);
 
 #ifdef __cplusplus

@@ -45,11 +45,37 @@ POINT_DTYPE = np.dtype([("pos", "<f4", (3,)), ("quat4", "<f4"), ("radius", "<f4"
 _lib = None
 
 
+def cgroup_cpu_limit():
+    """CPUs the container's cgroup grants (cpu.max quota / period), or None when unlimited / unknown.  On the GPU box
+    the affinity mask shows every host core while the quota is the share of one GPU; running one thread per visible
+    core then only makes the threads fight over the quota."""
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            quota, period = f.read().split()[:2]
+        if quota != "max":
+            return max(1, int(int(quota) / int(period)))
+    except (OSError, ValueError):
+        pass
+    try:
+        with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f:
+            quota = int(f.read())
+        with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+            period = int(f.read())
+        if quota > 0:
+            return max(1, quota // period)
+    except (OSError, ValueError):
+        pass
+    return None
+
+
 def usable_cpus(cap=16):
     try:
         n = len(os.sched_getaffinity(0))
     except AttributeError:
         n = os.cpu_count() or 1
+    lim = cgroup_cpu_limit()
+    if lim:
+        n = min(n, lim)
     env = os.environ.get("OMP_NUM_THREADS")
     if env:
         try:

@@ -493,7 +493,7 @@ def test_cli_error_behaviour(tmp_path):
 @pytest.fixture(scope="module")
 def full_workload():
     from bioem_amd.synthetic import Workload
-    W = Workload(N=224, nP=1000, nOrient=256, nEnv=5)     # full particle count / map size / CTF grid
+    W = Workload(N=224, nP=1000, nOrient=4608, nEnv=5)    # BASELINE config 2 at its own size
     yield W
     W.engine.close()
 
@@ -512,7 +512,7 @@ def test_full_size_sharding_invariance_and_planted_truth(full_workload):
     W = full_workload
     raw, full = run_workload(W, 0, W.nOrient)
     assert np.all(np.isfinite(full["Total"])) and np.all(full["Total"] >= 1.0)
-    parts = [run_workload(W, a, b)[0].copy() for a, b in [(0, 100), (100, 101), (101, 256)]]
+    parts = [run_workload(W, a, b)[0].copy() for a, b in [(0, 1700), (1700, 1701), (1701, W.nOrient)]]
     merged = eng.merge_host(parts, W.nP, W.nOrient, 0).view(eng.PROB_MAP_DTYPE)
     lf = np.log(full["Total"]) + full["Constoadd"]
     lm = np.log(merged["Total"]) + merged["Constoadd"]
@@ -528,11 +528,12 @@ def test_full_size_sharding_invariance_and_planted_truth(full_workload):
     assert np.mean(full["orient"] == truth) > 0.9
 
 
-def oracle_on_workload(W, sel, nO, algo=1):
+def oracle_on_workload(W, sel, nO, algo=1, angles=False, engine=None):
     """orientations [0, nO) x all CTFs x the particles `sel` of a synthetic workload through the CPU oracle
-    (from the engine's own particle spectra, so that the comparison path alone is under test)."""
+    (from the engine's own particle spectra, so that the comparison path alone is under test).  angles=True also
+    returns the oracle's angle table [nOrient][len(sel)]."""
     import ctypes as C
-    refFFT, sumRef, sumsqRef = W.engine.debug_particles()
+    refFFT, sumRef, sumsqRef = (engine or W.engine).debug_particles()
     nsel = len(sel)
     pd = orc.ParamDevice()
     for f, _ in orc.ParamDevice._fields_:
@@ -541,13 +542,19 @@ def oracle_on_workload(W, sel, nO, algo=1):
     for k in ("pos", "radius", "density"):
         pts[k] = W.points[k]
     want = np.zeros(nsel, dtype=orc.PROB_MAP_DTYPE)
+    wang = np.zeros((W.nOrient, nsel), dtype=orc.PROB_ANGLE_DTYPE) if angles else None
     L = orc.lib()
-    L.orc_init_prob(nsel, W.nOrient, 0, want.ctypes.data, None)
+    L.orc_init_prob(nsel, W.nOrient, int(pd.writeAngles) if angles else 0, want.ctypes.data,
+                    wang.ctypes.data if angles else None)
+    if not angles:
+        pd.writeAngles = 0
     rsel = np.ascontiguousarray(refFFT[sel])
     ssel, s2sel = np.ascontiguousarray(sumRef[sel]), np.ascontiguousarray(sumsqRef[sel])
     L.orc_run(C.byref(pd), algo, pts.ctypes.data, len(pts), W.NormDen, W.angles.ctypes.data, W.nOrient, 1, W.px, 0,
               0, W.nCTF, W.refCTF.ctypes.data, W.ctfParam.ctypes.data, nsel, rsel.ctypes.data, ssel.ctypes.data,
-              s2sel.ctypes.data, 0, nO, want.ctypes.data, None)
+              s2sel.ctypes.data, 0, nO, want.ctypes.data, wang.ctypes.data if angles else None)
+    if angles:
+        return want, orc.logp_constant(pd), wang
     return want, orc.logp_constant(pd)
 
 
@@ -571,6 +578,123 @@ def test_full_size_slice_against_oracle(full_workload):
     want, const = oracle_on_workload(W, sel, nO)
     _, got = run_workload(W, 0, nO)
     assert_workload_matches(got, want, const, sel)
+
+
+# ------------------------------------------------------------------------------------------------------
+# BASELINE config 3 at one GPU's share of the particle regime: 10 000 particles (2 GB of spectra, beyond the 256 MB
+# Infinity Cache), 2 x 5 CTFs, 224^2; 128 orientations = two batches of the device pipeline
+# ------------------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def config3_workload():
+    from bioem_amd.synthetic import Workload
+    W = Workload(N=224, nP=10000, nOrient=128, nEnv=5, nDefocus=2)
+    yield W
+    W.engine.close()
+
+
+def test_config3_share_properties_and_oracle_slice(config3_workload):
+    import bioem_amd.engine as eng
+    W = config3_workload
+    assert W.nCTF == 10 and W.engine.kernel_name == "k_compare_fast"
+    raw, full = run_workload(W, 0, W.nOrient)
+    assert np.all(np.isfinite(full["Total"])) and np.all(full["Total"] >= 1.0)
+    # shard-merge invariance: two orientation blocks with private probability blocks (the per-GPU split of config 3)
+    parts = [run_workload(W, a, b)[0].copy() for a, b in [(0, 64), (64, W.nOrient)]]
+    merged = eng.merge_host(parts, W.nP, W.nOrient, 0).view(eng.PROB_MAP_DTYPE)
+    lf = np.log(full["Total"]) + full["Constoadd"]
+    lm = np.log(merged["Total"]) + merged["Constoadd"]
+    assert np.abs(lf - lm).max() <= 1e-9 * np.abs(lf).max()
+    for k in ("orient", "conv", "cent_x", "cent_y"):
+        assert np.array_equal(full[k], merged[k])
+    # bit-identical rerun (no atomics / races on the hot path at 40 000 resident blocks)
+    raw2, _ = run_workload(W, 0, W.nOrient)
+    assert raw.tobytes() == raw2.tobytes()
+    # planted truth: particle p = orientation (7919 p) mod 128, CTF p mod 10
+    truth_o = (7919 * np.arange(W.nP)) % W.nOrient
+    assert np.mean(full["orient"] == truth_o) > 0.9
+    assert np.mean(full["conv"] == np.arange(W.nP) % W.nCTF) > 0.5
+    # the CPU oracle on a slice: 8 particles from both ends and the middle of the stack x 6 orientations x 10 CTFs
+    sel = [0, 1, 2, 4999, 5000, 9997, 9998, 9999]
+    want, const = oracle_on_workload(W, sel, 6)
+    _, got = run_workload(W, 0, 6)
+    assert_workload_matches(got, want, const, sel)
+
+
+# ------------------------------------------------------------------------------------------------------
+# BASELINE config 5 shape: 256^2 particles delivered by the MRC reader (--ReadMRC --ReadMultipleMRC path of the
+# host layer), 1 000 particles x 2 304 orientations, WRITE_PROB_ANGLES, two orientation shards with sharded angle
+# tables and device top-K
+# ------------------------------------------------------------------------------------------------------
+def test_config5_shape_two_shards_device_top_k(tmp_path):
+    import bioem_amd.engine as eng
+    from bioem_amd import hostlib
+    from bioem_amd.synthetic import Workload
+    from golden_util import write_mrc_stack
+    K, nO, nP, N = 10, 2304, 1000, 256
+    W = Workload(N=N, nP=nP, nOrient=nO, nEnv=2, nDefocus=2, write_angles=K)        # one shard handle over [0, nO)
+    assert W.nCTF == 4 and W.engine.shard == (0, nO)
+    # the particle stack as raw counts in two MRC stacks + list file; the reader transposes and z-scores
+    rawcounts = (3.0 * np.transpose(W.maps, (0, 2, 1)) + 7.0).astype(np.float32)
+    write_mrc_stack(str(tmp_path / "a.mrc"), rawcounts[:400])
+    write_mrc_stack(str(tmp_path / "b.mrc"), rawcounts[400:])
+    with open(tmp_path / "list.txt", "w") as f:
+        f.write(str(tmp_path / "a.mrc") + "\n" + str(tmp_path / "b.mrc") + "\n")
+    maps = hostlib.read_particles(str(tmp_path / "list.txt"), N, mode=2, cap=nP)
+    # (the reader's mean / variance are sequential float sums over 65 536 pixels, map.cpp:831-845: ~5e-4 off)
+    assert maps.shape == (nP, N, N) and np.abs(maps - W.maps).max() <= 3e-3
+    numconst = orc.logp_constant(W.pd)
+
+    def shard(o0, o1):
+        E = eng.Engine(W.pd, nP, nO, W.nCTF, algo=1, device=0, shard=(o0, o1))
+        E.upload_particle_maps(maps)
+        E.upload_ctf(W.refCTF, W.ctfParam)
+        E.upload_model(W.points, W.NormDen, W.px)
+        E.upload_orientations(W.angles, True)
+        raw, pmap = run_shard(E, o0, o1)
+        return E, raw.copy(), E.topk_angles(K, numconst)
+
+    Ea, rawa, ca = shard(0, nO // 2)
+    Eb, rawb, cb = shard(nO // 2, nO)
+    E1, raw1, c1 = shard(0, nO)
+    one = raw1.view(eng.PROB_MAP_DTYPE)
+    merged = eng.merge_host([rawa, rawb], nP, 0, 0).view(eng.PROB_MAP_DTYPE)
+    la = np.log(one["Total"]) + one["Constoadd"]
+    lb = np.log(merged["Total"]) + merged["Constoadd"]
+    assert np.abs(la - lb).max() <= 1e-9 * np.abs(la).max()
+    for k in ("orient", "conv", "cent_x", "cent_y"):
+        assert np.array_equal(one[k], merged[k])
+    cm = eng.merge_topk_host([ca, cb])
+    assert np.array_equal(cm["orient"], c1["orient"])           # K best of the union == K best of the whole table
+    assert np.abs(cm["logp"] - c1["logp"]).max() <= 1e-9 * np.abs(c1["logp"]).max()
+    assert np.all(np.diff(c1["logp"], axis=1) <= 0)             # best first
+    truth = (7919 * np.arange(nP)) % nO
+    assert np.mean(c1["orient"][:, 0] == truth) > 0.9           # the planted orientation leads the list
+    # oracle on a slice: 8 particles x the first 12 orientations, K best of those 12
+    sel = [0, 1, 2, 3, 500, 501, 998, 999]
+    for E in (Ea, Eb):
+        E.close()
+    Es = eng.Engine(W.pd, nP, nO, W.nCTF, algo=1, device=0, shard=(0, 12))
+    Es.upload_particle_maps(maps)
+    Es.upload_ctf(W.refCTF, W.ctfParam)
+    Es.upload_model(W.points, W.NormDen, W.px)
+    Es.upload_orientations(W.angles, True)
+    _, got = run_shard(Es, 0, 12)
+    cs = Es.topk_angles(K, numconst)
+    want, const, wang = oracle_on_workload(W, sel, 12, angles=True, engine=Es)
+    assert_workload_matches(got, want, const, sel)
+    import heapq
+    for i, p in enumerate(sel):
+        q = []
+        for io in range(12):
+            pa = wang[io, i]
+            heapq.heappush(q, (float(np.log(pa["forAngles"]) + pa["ConstAngle"] + numconst), io))
+        best = sorted(q, reverse=True)[:K]
+        assert [io for _, io in best] == [int(v) for v in cs[p]["orient"]]
+        for (lp, _), c in zip(best, cs[p]):     # same bound as the particle entries: 2e-2 or two float spacings of log P
+            assert abs(lp - c["logp"]) <= max(ABS_TOL, 2.0 * float(np.spacing(np.float32(abs(lp)))))
+    Es.close()
+    E1.close()
+    W.engine.close()
 
 
 # image sizes by the register-FFT length R the comparison kernel picks (N = N1 * R: the power-of-two part of N up to
