@@ -106,6 +106,11 @@ struct bioem_hip_ctx
   std::vector<int> tileCenter, tileValid; // per axis tile: centre (in window rows) and number of rows inside the window
   int *dDispLocal = nullptr, *dTileCenter = nullptr, *dTileValid = nullptr, *dRankOfRow = nullptr;
   int wideWPC = 0; // k_compare_wide: waves per comparison (= y-tiles per launch), 0 = one launch per tile
+  // k_compare_wide2 (compare_wide2.hpp): wide window in ONE launch per batch -- column transforms shared by the four
+  // waves of a comparison, row FFT
+  bool wide2 = false;
+  int w2NRW = 0, w2NBLK = 0, w2TS = 0, w2Rows2 = 0, nyqWD = 0;
+  float2 *dTwk2 = nullptr; // [N1][nd] recombination twiddles exp(2 pi i dx k1 / N), rows in sorted order
   float2 *dConvShift = nullptr;
   Partial *dPartTiles = nullptr;
   bool nyq = false;               // Nyquist column handled outside the 64-column blocks (N/2 a multiple of 64)
@@ -201,6 +206,7 @@ struct bioem_hip_ctx
 #include "compare_args.hpp"
 #include "compare_fast.hpp"
 #include "compare_wide.hpp"
+#include "compare_wide2.hpp"
 #include "compare_generic.hpp"
 #include "compare_rows.hpp"
 #include "fold_kernels.hpp"
@@ -345,6 +351,40 @@ size_t wide_lds_bytes(int N, int H, int wpc, bool nyq)
   return (size_t) ((N + 2) & ~1) * 8 + 256 + 1024 + (size_t) (4 / wpc) * nblk * 21 * 66 * 8;
 }
 
+// k_compare_wide2 instantiations: every register-FFT length; (rows per wave, column blocks) = (32, 1) or (21, 2)
+template <int R>
+fast_kernel_t wide2_kernel_r(int nblk, bool nyq)
+{
+  if constexpr (R == 32)
+  {
+    if (nyq)
+      return nblk == 1 ? k_compare_wide2<32, 32, 1, true> : k_compare_wide2<32, 21, 2, true>;
+  }
+  return nblk == 1 ? k_compare_wide2<R, 32, 1, false> : k_compare_wide2<R, 21, 2, false>;
+}
+fast_kernel_t wide2_kernel(int R, int nblk, bool nyq)
+{
+  switch (R)
+  {
+  case 32: return wide2_kernel_r<32>(nblk, nyq);
+  case 16: return wide2_kernel_r<16>(nblk, nyq);
+  case 8: return wide2_kernel_r<8>(nblk, nyq);
+  case 4: return wide2_kernel_r<4>(nblk, nyq);
+  case 2: return wide2_kernel_r<2>(nblk, nyq);
+  case 30: return wide2_kernel_r<30>(nblk, nyq);
+  case 20: return wide2_kernel_r<20>(nblk, nyq);
+  case 18: return wide2_kernel_r<18>(nblk, nyq);
+  case 12: return wide2_kernel_r<12>(nblk, nyq);
+  case 10: return wide2_kernel_r<10>(nblk, nyq);
+  default: return wide2_kernel_r<6>(nblk, nyq);
+  }
+}
+size_t wide2_lds_bytes(int N, int R, int rows2, int ts)
+{ // tables (twiddles, visiting ranks, log table, wave results) + max(four FFT-output slots, T block)
+  const size_t slots = (size_t) 4 * R * 64 * 8, tblock = (size_t) rows2 * ts * 8;
+  return (size_t) ((N + 2) & ~1) * 8 + 512 + 1024 + 128 + std::max(slots, tblock);
+}
+
 template <int WD>
 fast_kernel_t rows_kernel_g(int gs)
 {
@@ -419,7 +459,27 @@ int launch_compare_fold(bioem_hip_ctx *h, const BatchBuf &bb, int nOC, int orien
     return 1;
   }
   HIP_CHECK(h, hipEventRecord(e0, h->stream));
-  if (h->fast || h->rowsK)
+  if (h->wide2)
+  {
+    CompareArgs aw = a;
+    aw.twk = h->dTwk2;
+    aw.ts = h->w2TS;
+    aw.nyqWD = h->nyqWD;
+    if (h->nyq)
+    {
+      const dim3 gridq((unsigned) (((size_t) (h->nMaps + 15) / 16) * ((nOC + 15) / 16)));
+      if (h->nyqWD == 20)
+        hipLaunchKernelGGL(k_nyquist_rows<20>, gridq, dim3(256), 0, h->stream, aw);
+      else if (h->nyqWD == 31)
+        hipLaunchKernelGGL(k_nyquist_rows<31>, gridq, dim3(256), 0, h->stream, aw);
+      else
+        hipLaunchKernelGGL(k_nyquist_rows<42>, gridq, dim3(256), 0, h->stream, aw);
+    }
+    const size_t lds = wide2_lds_bytes(h->N, 2 * h->fast, h->w2Rows2, h->w2TS);
+    hipLaunchKernelGGL(wide2_kernel(2 * h->fast, h->w2NBLK, h->nyq), dim3((unsigned) ((size_t) nOC * h->nMaps)), dim3(256),
+                       lds, h->stream, aw);
+  }
+  else if (h->fast || h->rowsK)
   {
     const int NW = 2 * h->winD + 1;
     const size_t lds = fast_lds_bytes(h->N, NW, 4, h->fast ? fast_half_t(h->winD, 2 * h->fast) : false);
@@ -813,7 +873,50 @@ static int create_impl(bioem_hip_handle *out, int device, const bioem_hip_param_
   // symmetric set {gs*m, |m| <= mD}
   h->tileT = 0;
   h->tilesPerAxis = 1;
-  if (N >= 8 && (mD > 15 || h->nd > 31) && h->nd == 2 * mD + 1 && !getenv("BIOEM_NO_TILES"))
+  // wide windows, first choice: k_compare_wide2 (one launch per batch, shared column transforms, row FFT).  Needs an
+  // even image size with at most two 64-column blocks, at most 32 (one block) / 21 (two blocks) window rows per wave,
+  // and its T block [rows][H] in LDS
+  if (N % 2 == 0 && N >= 8 && (mD > 15 || h->nd > 31) && h->nd == 2 * mD + 1 && !getenv("BIOEM_NO_WIDE2"))
+  {
+    int R = (N % 32 == 0) ? 32 : (N % 16 == 0) ? 16 : (N % 8 == 0) ? 8 : (N % 4 == 0) ? 4 : 2;
+    if (R < 8 && !getenv("BIOEM_POW2_FFT"))
+    {
+      static const int mixed[] = {30, 20, 18, 12, 10, 6};
+      for (int r : mixed)
+        if (N % r == 0 && r > R)
+        {
+          R = r;
+          break;
+        }
+    }
+    const bool nyq = BIOEM_NYQUIST_SPLIT && (N / 2) % 64 == 0;
+    const int nblk = nyq ? (h->H - 1) / 64 : (h->H + 63) / 64;
+    const int rpw = (h->nd + 3) / 4;
+    const int rows2 = 2 * ((h->nd + 1) / 2);
+    int ts = h->H; // row stride = 4 mod 16 float2: the (row pair, k1) lanes of the row pass spread over the banks
+    while (ts % 16 != 4)
+      ts++;
+    const int N1 = N / R;
+    if (nblk <= 2 && rpw <= (nblk == 1 ? 32 : 21) && N1 <= 32 && h->nd <= 128 && (!nyq || mD <= 42) &&
+        wide2_lds_bytes(N, R, rows2, ts) <= 160 * 1024)
+    {
+      h->wide2 = true;
+      h->fast = R / 2;
+      h->N1 = N1;
+      h->nyq = nyq;
+      h->w2NBLK = nblk;
+      h->w2NRW = nblk == 1 ? 32 : 21;
+      h->w2TS = ts;
+      h->w2Rows2 = rows2;
+      h->nyqWD = mD <= 20 ? 20 : mD <= 31 ? 31 : 42;
+      if (nyq)
+        h->winD = h->nyqWD; // sizes the Nyquist pre-kernel's tables
+      HIP_CHECK(h, hipFuncSetAttribute(reinterpret_cast<const void *>(wide2_kernel(R, nblk, nyq)),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int) wide2_lds_bytes(N, R, rows2, ts)));
+    }
+  }
+  if (!h->wide2 && N >= 8 && (mD > 15 || h->nd > 31) && h->nd == 2 * mD + 1 && !getenv("BIOEM_NO_TILES"))
   {
     const int W = h->nd;
     // launches^2 x the measured cost of one launch of the 21- / 27- / 31-row kernel (ms at 224^2)
@@ -852,8 +955,9 @@ static int create_impl(bioem_hip_handle *out, int device, const bioem_hip_param_
       h->tileValid.push_back(std::min(h->tileT, W - k * h->tileT));        // rows of tile k inside the window
     }
   }
-  h->fast = 0;
-  if (N % 2 == 0 && N >= 8 && ((maxD / h->gs <= 15 && h->nd <= 31) || h->tileT))
+  if (!h->wide2)
+    h->fast = 0;
+  if (!h->wide2 && N % 2 == 0 && N >= 8 && ((maxD / h->gs <= 15 && h->nd <= 31) || h->tileT))
   {
     int R = (N % 32 == 0) ? 32 : (N % 16 == 0) ? 16 : (N % 8 == 0) ? 8 : (N % 4 == 0) ? 4 : 2;
     // 31-row window: a 16-point register FFT keeps the kernel at 3 waves per SIMD (see fast_half_t); sizes that
@@ -873,8 +977,11 @@ static int create_impl(bioem_hip_handle *out, int device, const bioem_hip_param_
     }
     h->fast = R / 2;
   }
-  h->N1 = h->fast ? N / (2 * h->fast) : 0;
-  h->nyq = BIOEM_NYQUIST_SPLIT && h->fast && (N / 2) % 64 == 0;
+  if (!h->wide2)
+  {
+    h->N1 = h->fast ? N / (2 * h->fast) : 0;
+    h->nyq = BIOEM_NYQUIST_SPLIT && h->fast && (N / 2) % 64 == 0;
+  }
   // no even factor (odd N) but a window of at most 31 rows: k_compare_rows (reference layout, direct column sums,
   // the fast kernel's T exchange / window / posterior) instead of the generic kernel
   h->rowsK = !h->fast && N >= 8 && (h->tileT || (mD <= 15 && h->nd <= 31)) && !getenv("BIOEM_NO_ROWS_KERNEL");
@@ -896,6 +1003,7 @@ static int create_impl(bioem_hip_handle *out, int device, const bioem_hip_param_
     h->wideWPC = 0;
   }
   // LDS budget check
+  if (!h->wide2)
   {
     // generic kernel: as many waves per block (4, 2, 1) as its per-wave T block [nd][H] lets fit
     h->genericWaves = 4;
@@ -1014,6 +1122,19 @@ static int create_impl(bioem_hip_handle *out, int device, const bioem_hip_param_
     HIP_CHECK(h, hipEventCreateWithFlags(&h->cmpDone[i], hipEventDisableTiming));
   }
 
+  if (h->wide2)
+  { // recombination twiddles exp(2 pi i dx k1 / N) for the window rows in sorted order, dx = (m - mD) gs
+    std::vector<float2> t2((size_t) h->N1 * h->nd);
+    for (int k1 = 0; k1 < h->N1; k1++)
+      for (int m = 0; m < h->nd; m++)
+      {
+        const long long dx = (long long) (m - mD) * h->gs;
+        const double ang = 2.0 * M_PI * (double) (((dx * k1) % N + N) % N) / (double) N;
+        t2[(size_t) k1 * h->nd + m] = make_float2((float) cos(ang), (float) sin(ang));
+      }
+    HIP_CHECK(h, hipMalloc(&h->dTwk2, sizeof(float2) * t2.size()));
+    HIP_CHECK(h, hipMemcpy(h->dTwk2, t2.data(), sizeof(float2) * t2.size(), hipMemcpyHostToDevice));
+  }
   std::vector<float2> tw(N + 1);
   std::vector<double2> twd(N);
   for (int k = 0; k <= N; k++)
@@ -1097,7 +1218,7 @@ int bioem_hip_destroy(bioem_hip_handle h)
                   h->dScratch, h->dConv,    h->dParams,   h->dPartials, h->dProb,
                   h->dProjReal2, h->dTempDen2, h->dRowSpec2, h->dSpecRef2, h->dScratch2, h->dConv2, h->dParams2,
                   h->dTnyq, h->dTwNyq, h->dPartTiles, h->dConvShift, h->dDispLocal, h->dRankOfRow, h->dTileCenter, h->dTileValid,
-                  h->dCand, h->dSend, h->dRecv, h->dMerged};
+                  h->dCand, h->dSend, h->dRecv, h->dMerged, h->dTwk2};
   for (void *p : ptrs)
     if (p)
       hipFree(p);
@@ -1771,12 +1892,25 @@ int bioem_hip_reset_kernel_stats(bioem_hip_handle h)
   return 0;
 }
 
+#ifdef BIOEM_W2_STAMPS
+// diagnostic build only: summed shader cycles per phase of k_compare_wide2 (and reset)
+int bioem_hip_debug_w2_stamps(unsigned long long *out8)
+{
+  unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (hipDeviceSynchronize() != hipSuccess || hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_w2_stamps), sizeof(z)) != hipSuccess)
+    return 1;
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_w2_stamps), z, sizeof(z)) == hipSuccess ? 0 : 1;
+}
+#endif
+
 int bioem_hip_uses_fast_path(bioem_hip_handle h) { return h && h->fast ? 1 : 0; }
 
 const char *bioem_hip_kernel_name(bioem_hip_handle h)
 {
   if (!h)
     return "";
+  if (h->wide2)
+    return "k_compare_wide2";
   if (h->fast)
     return (h->tileT && h->wideWPC) ? "k_compare_wide" : "k_compare_fast";
   return h->rowsK ? (h->oddR ? "k_compare_oddfft" : "k_compare_rows") : "k_compare_generic";
@@ -1788,7 +1922,9 @@ const char *bioem_hip_kernel_signature(bioem_hip_handle h)
     return "";
   static thread_local char buf[96];
   const char *nq = h->nyq ? "true" : "false";
-  if (h->fast && h->tileT && h->wideWPC)
+  if (h->wide2)
+    snprintf(buf, sizeof(buf), "k_compare_wide2<%d, %d, %d, %s>", 2 * h->fast, h->w2NRW, h->w2NBLK, nq);
+  else if (h->fast && h->tileT && h->wideWPC)
     snprintf(buf, sizeof(buf), "k_compare_wide<%d, %d, %d, %s>", 2 * h->fast, h->gs, h->wideWPC, nq);
   else if (h->fast)
     snprintf(buf, sizeof(buf), "k_compare_fast<%d, %d, %s, %d>", h->winD, 2 * h->fast, nq, h->gs);

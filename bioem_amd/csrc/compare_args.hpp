@@ -31,6 +31,9 @@ struct CompareArgs
   int yTile0, nTiles;
   const int *tileCenter, *tileValid;
   size_t tileStride;
+  // k_compare_wide2: row stride of the LDS T block (float2 units); window half width of the k_nyquist_rows
+  // instantiation that filled tnyq (its rows run -nyqWD..nyqWD)
+  int ts, nyqWD;
   PD pd;
 };
 

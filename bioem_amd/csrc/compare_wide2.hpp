@@ -1,0 +1,408 @@
+// compare_wide2.hpp -- wide translation windows (more than 31 offsets per axis) with a row FFT: one comparison per block
+// Part of libbioem_hip.so; included by bioem_hip.hip only (one translation unit, anonymous namespace).
+#ifndef BIOEM_COMPARE_WIDE2_HPP
+#define BIOEM_COMPARE_WIDE2_HPP
+
+namespace
+{
+
+// ------------------------------------------------------------------------------------------------
+// The reference reads any window out of one full c2r (bioem.cpp:1458, doc/index.rst:1355-1360: cost "almost
+// independent" of the displacement count).  The tiled kernels pay the column transforms once per 21-row x-tile and a
+// direct O(W^2 H) row pass; this kernel pays every transform once and runs the row pass as an FFT, too:
+//
+//   column pass  T[dx][ky] = sum_k1 w_N^(dx k1) y_k1[dx mod R][ky],  y_k1 = IFFT_R over k2 of X[N1 k2 + k1][ky]
+//     The four waves of the block work on ONE comparison.  In rounds of four (k1, column block) steps every wave
+//     forms the spectrum product and the R-point register FFT of one step (lane = ky, as in k_compare_fast) and parks
+//     the R outputs in an LDS slot; after a barrier every wave folds all four slots into ITS quarter of the window
+//     rows (<= NRW rows: 2 NRW NBLK accumulators in registers).  Product and FFT are paid once per comparison, not
+//     once per x-tile.
+//   T -> LDS     [rows][TS] float2, unweighted (the c2r weights are folded into the Hermitian extension below); the
+//     slots are dead by then and share the space.
+//   row pass     cc[dx][dy] = Re sum_ky w_ky T[dx][ky] e^(2 pi i ky dy / N)  (FFTW c2r: columns 0 and N/2 enter once,
+//     real part only).  Two rows a, b at a time as ONE complex length-N inverse transform of U = G_a + i G_b, with G
+//     the Hermitian extension of the half spectrum (G[N - ky] = conj(T[ky]), Im G[0] = Im G[N/2] = 0): the result is
+//     cc_a + i cc_b.  Same N = N1 R split: lane = (row pair, k1) runs one R-point register FFT over k2 (for k2 < R/2
+//     the inputs are direct, beyond mirrored -- a compile-time property of k2), writes y[n][k1] over the pair's own
+//     rows, then lanes = dy recombine  S[dy] = sum_k1 w_N^(dy k1) y[dy mod R][k1]  and run the posterior for
+//     (a, dy) = Re S and (b, dy) = Im S.  Pairs are private to a wave: no block barrier inside the row pass.
+//   one Partial per comparison (the four waves' log-sum-exp states merged in wave order), ids = global visiting
+//     ranks: the fold kernels see what k_compare_fast would have produced for this window.
+// Window rows m = 0..nd-1 hold dx = (m - mD) gs (sorted); dinv[m] is the visiting rank of that offset in the
+// reference's order (bioem_algorithm.h:156-197 / bioem.cpp:1477-1485).
+// LDS: tables + max(4 R 512 B, rows2 TS 8 B): 76 KiB at 224^2 +-40 px -> two blocks per CU.
+// ------------------------------------------------------------------------------------------------
+// diagnostic build only (-DBIOEM_W2_STAMPS, never shipped): shader-clock cycles per phase of wave 0, summed over blocks
+#ifdef BIOEM_W2_STAMPS
+__device__ unsigned long long g_w2_stamps[8];
+#define W2_STAMP(k)                                                                                                \
+  do                                                                                                               \
+  {                                                                                                                \
+    const unsigned long long now_ = __builtin_amdgcn_s_memtime();                                                  \
+    if (threadIdx.x == 0)                                                                                          \
+      atomicAdd(&g_w2_stamps[k], now_ - stamp_);                                                                   \
+    stamp_ = now_;                                                                                                 \
+  } while (0)
+#else
+#define W2_STAMP(k)
+#endif
+
+// wave-uniform table reads through the constant address space: always scalar loads (the uniform global loads of this
+// kernel were otherwise emitted as vector loads, one L2 round trip each)
+typedef const float2 __attribute__((address_space(4))) *const_float2_ptr;
+__device__ __forceinline__ const_float2_ptr as_constant(const float2 *p)
+{
+  return (const_float2_ptr) (unsigned long long) p;
+}
+
+template <int R, int NRW, int NBLK, bool NYQ>
+__global__ __launch_bounds__(256, 2) void k_compare_wide2(const CompareArgs a)
+{
+  constexpr int R2 = R / 2;
+  // depth of the operand ring (divides R2): the first RD row pairs of a wave's next step are issued before the
+  // round's barriers.  With only two waves per SIMD the ring is what hides the L2 latency: as deep as registers allow
+#ifndef BIOEM_W2_RING
+#define BIOEM_W2_RING 4
+#endif
+  constexpr int RD = (R2 % BIOEM_W2_RING == 0) ? BIOEM_W2_RING
+                     : (R2 % 4 == 0)           ? 4
+                     : (R2 % 5 == 0)           ? 5
+                     : (R2 % 3 == 0)           ? 3
+                     : (R2 % 2 == 0)           ? 2
+                                               : 1;
+  extern __shared__ __align__(16) unsigned char smem[];
+  const int N = a.N, H = a.H, N1 = a.N1, nd = a.nd, TS = a.ts;
+  float2 *twl = reinterpret_cast<float2 *>(smem);
+  int *dinv = reinterpret_cast<int *>(smem + (size_t) ((N + 2) & ~1) * 8);                 // nd ints (512 B reserved)
+  double2 *ltab = reinterpret_cast<double2 *>(smem + (size_t) ((N + 2) & ~1) * 8 + 512);    // 64 entries
+  LseF *lsew = reinterpret_cast<LseF *>(smem + (size_t) ((N + 2) & ~1) * 8 + 512 + 1024);   // 4 wave results (128 B)
+  float2 *U = reinterpret_cast<float2 *>(smem + (size_t) ((N + 2) & ~1) * 8 + 512 + 1024 + 128);
+  const int wave = __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6));
+  const int lane = threadIdx.x & 63;
+  const int gs = a.gs, mD = a.maxD / gs;
+
+  for (int t = threadIdx.x; t <= N; t += blockDim.x)
+    twl[t] = a.tw[t];
+  for (int t = threadIdx.x; t < nd; t += blockDim.x)
+    dinv[a.disp[t] / gs + mD] = t; // a.disp = offsets in visiting order
+  for (int t = threadIdx.x; t < 64; t += blockDim.x)
+    ltab[t] = a.ltab[t];
+
+  int p, oc;
+  { // block order of k_compare_fast with one comparison per block: particle chunks, particle index fastest
+    const int per = a.pchunk * a.nOC;
+    int c = blockIdx.x / per;
+    const int nch = (a.nMaps + a.pchunk - 1) / a.pchunk;
+    c = min(c, nch - 1);
+    const int rem = blockIdx.x - c * per;
+    const int pc = min(a.pchunk, a.nMaps - c * a.pchunk);
+    oc = rem / pc;
+    p = c * a.pchunk + (rem - oc * pc);
+  }
+  const size_t M = (size_t) N * H;
+  const auto rsrcF = __builtin_amdgcn_make_buffer_rsrc(const_cast<float2 *>(a.ref + (size_t) p * M), 0,
+                                                       (int) (M * sizeof(float2)), 0x00020000);
+  const auto rsrcC = __builtin_amdgcn_make_buffer_rsrc(const_cast<float2 *>(a.conv + (size_t) oc * M), 0,
+                                                       (int) (M * sizeof(float2)), 0x00020000);
+
+#ifdef BIOEM_W2_STAMPS
+  unsigned long long stamp_ = __builtin_amdgcn_s_memtime();
+#endif
+  // ---------------- column pass ----------------
+  const int rpw = (nd + 3) >> 2; // window rows per wave
+  const int r0 = wave * rpw;
+  const int nrows = max(0, min(rpw, nd - r0));
+  const int nblk = NYQ ? (H - 1) / 64 : (H + 63) / 64;
+  const unsigned rowbytes = (unsigned) H * 16u;
+  float Tr[NBLK][NRW], Ti[NBLK][NRW];
+#pragma unroll
+  for (int b = 0; b < NBLK; b++)
+#pragma unroll
+    for (int d = 0; d < NRW; d++)
+    {
+      Tr[b][d] = 0.f;
+      Ti[b][d] = 0.f;
+    }
+  __syncthreads();
+  // operand ring of this wave's steps (blk, k1 = base + wave): the first RD row pairs of the NEXT step are issued
+  // before the round's barriers, so they fly while the round's slots are folded
+  u32x4 rf[RD], rc[RD];
+  bool primed = false;
+  auto prime = [&](int k1n, unsigned laneoffn) {
+#pragma unroll
+    for (int t = 0; t < RD; t++)
+    {
+      rf[t] = __builtin_amdgcn_raw_buffer_load_b128(rsrcF, laneoffn, (unsigned) (k1n * R2 + t) * rowbytes, 0);
+      rc[t] = __builtin_amdgcn_raw_buffer_load_b128(rsrcC, laneoffn, (unsigned) (k1n * R2 + t) * rowbytes, 0);
+    }
+  };
+#pragma unroll
+  for (int blk = 0; blk < NBLK; blk++)
+  {
+    if (blk < nblk)
+    {
+      const int ky = blk * 64 + lane;
+      const unsigned laneoff = (unsigned) (ky < H ? ky : H - 1) * 16u;
+      const int kyn = ky + 64;
+      const unsigned laneoff_next = (unsigned) (kyn < H ? kyn : H - 1) * 16u;
+      for (int base = 0; base < N1; base += 4)
+      {
+        const int k1 = base + wave;
+        if (k1 < N1)
+        { // this wave's step of the round: product + register FFT, outputs to slot `wave`
+          float xr[R], xi[R];
+          if (!primed)
+            prime(k1, laneoff);
+#pragma unroll
+          for (int k2p = 0; k2p < R2; k2p++)
+          {
+            const float4 f = as_float4(rf[k2p % RD]);
+            const float4 c = as_float4(rc[k2p % RD]);
+            // X = conv * conj(ref)   (bioem.cpp:1452-1455)
+            xr[FFT_IN(2 * k2p)] = fmaf(c.x, f.x, c.y * f.y);
+            xi[FFT_IN(2 * k2p)] = fmaf(c.y, f.x, -(c.x * f.y));
+            xr[FFT_IN(2 * k2p + 1)] = fmaf(c.z, f.z, c.w * f.w);
+            xi[FFT_IN(2 * k2p + 1)] = fmaf(c.w, f.z, -(c.z * f.w));
+            if (k2p + RD < R2)
+            {
+              rf[k2p % RD] = __builtin_amdgcn_raw_buffer_load_b128(rsrcF, laneoff,
+                                                                  (unsigned) (k1 * R2 + k2p + RD) * rowbytes, 0);
+              rc[k2p % RD] = __builtin_amdgcn_raw_buffer_load_b128(rsrcC, laneoff,
+                                                                  (unsigned) (k1 * R2 + k2p + RD) * rowbytes, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+          }
+          // next step of this wave: same block four k1 further, or the first one of the next column block
+          primed = false;
+          if (k1 + 4 < N1)
+          {
+            prime(k1 + 4, laneoff);
+            primed = true;
+          }
+          else if (blk + 1 < nblk && wave < N1)
+          {
+            prime(wave, laneoff_next);
+            primed = true;
+          }
+          FFT_RUN(xr, xi);
+          float2 *slot = U + (size_t) wave * R * 64 + lane;
+#pragma unroll
+          for (int n = 0; n < R; n++)
+            slot[n * 64] = make_float2(xr[FFT_OUT(n)], xi[FFT_OUT(n)]);
+        }
+        __syncthreads();
+        W2_STAMP(5);
+        // fold the round's slots into this wave's rows:  T[dx] += w_N^(dx k1) * y_k1[dx mod R]
+        // (all NRW accumulators, rows beyond this wave's share clamped to its last row and never stored)
+        for (int s = 0; s < 4; s++)
+        {
+          const int k1s = base + s;
+          if (k1s < N1)
+          {
+            const const_float2_ptr twk = as_constant(a.twk) + (size_t) k1s * nd;
+            const float2 *ys = U + (size_t) s * R * 64 + lane;
+            float2 w[NRW], y[NRW];
+#pragma unroll
+            for (int d = 0; d < NRW; d++)
+            {
+              const int m = min(r0 + d, nd - 1);
+              const int dx = (m - mD) * gs;
+              const int res = ((dx % R) + R) % R;
+              w[d] = make_float2(twk[m].x, twk[m].y);
+              y[d] = ys[res * 64];
+            }
+#pragma unroll
+            for (int d = 0; d < NRW; d++)
+            {
+              float tr = Tr[blk][d], ti = Ti[blk][d];
+              tr = fmaf(y[d].x, w[d].x, tr);
+              tr = fmaf(-y[d].y, w[d].y, tr);
+              ti = fmaf(y[d].x, w[d].y, ti);
+              ti = fmaf(y[d].y, w[d].x, ti);
+              Tr[blk][d] = tr;
+              Ti[blk][d] = ti;
+            }
+          }
+        }
+        __syncthreads();
+        W2_STAMP(6);
+      }
+    }
+  }
+  W2_STAMP(0);
+  // ---------------- T -> LDS (the slots are dead) ----------------
+  float2 *Tl = U;
+#pragma unroll
+  for (int blk = 0; blk < NBLK; blk++)
+  {
+    const int ky = blk * 64 + lane;
+    if (blk < nblk && ky < (NYQ ? H - 1 : H))
+    {
+#pragma unroll
+      for (int d = 0; d < NRW; d++)
+        if (d < nrows)
+          Tl[(size_t) (r0 + d) * TS + ky] = make_float2(Tr[blk][d], Ti[blk][d]);
+    }
+  }
+  if (NYQ && lane < nrows)
+  { // Nyquist column from k_nyquist_rows: rows -nyqWD..nyqWD of Re T[.][N/2] (the imaginary part never enters)
+    const int NWQ = 2 * a.nyqWD + 1;
+    const float *tq = a.tnyq + ((size_t) p * a.ldPart + oc) * NWQ;
+    Tl[(size_t) (r0 + lane) * TS + N / 2] = make_float2(tq[r0 + lane - mD + a.nyqWD], 0.f);
+  }
+  if ((nd & 1) && wave == 3)
+    for (int c = lane; c < H; c += 64) // odd row count: the last pair's second row is empty
+      Tl[(size_t) nd * TS + c] = make_float2(0.f, 0.f);
+  __syncthreads();
+
+  W2_STAMP(1);
+  // ---------------- row pass: pairs of rows, private to a wave ----------------
+  const int npairs = (nd + 1) >> 1;
+  const int ppw = (npairs + 3) >> 2;
+  const int pj0 = wave * ppw;
+  const int npw = max(0, min(ppw, npairs - pj0));
+  const int PPP = 64 / N1; // pairs per pass
+  for (int pass0 = 0; pass0 < npw; pass0 += PPP)
+  {
+    const int pl = lane / N1, k1 = lane - pl * N1;
+    const bool act = pl < PPP && pass0 + pl < npw;
+    const int pair = pj0 + (act ? pass0 + pl : 0);
+    const float2 *ra = Tl + (size_t) (2 * pair) * TS;
+    const float2 *rb = ra + TS;
+    const float s0 = k1 == 0 ? 0.f : 1.f; // columns 0 and N/2: imaginary parts do not enter (FFTW c2r)
+    float xr[R], xi[R];
+#pragma unroll
+    for (int k2 = 0; k2 < R; k2++)
+    {
+      float2 ta, tb;
+      float s;
+      if (k2 < R2)
+      { // ky = N1 k2 + k1 <= N/2: the stored half
+        ta = ra[N1 * k2 + k1];
+        tb = rb[N1 * k2 + k1];
+        s = k2 == 0 ? s0 : 1.f;
+      }
+      else
+      { // ky > N/2 (or ky = N/2 for k2 = R/2, k1 = 0): G[ky] = conj(T[N - ky]),  N - ky = N1 (R - k2) - k1
+        ta = ra[N1 * (R - k2) - k1];
+        tb = rb[N1 * (R - k2) - k1];
+        s = k2 == R2 ? -s0 : -1.f;
+      }
+      // U = G_a + i G_b with Im G = s Im T
+      xr[FFT_IN(k2)] = fmaf(-s, tb.y, ta.x);
+      xi[FFT_IN(k2)] = fmaf(s, ta.y, tb.x);
+    }
+    FFT_RUN(xr, xi);
+    if (act)
+    {
+      float2 *yp = const_cast<float2 *>(ra) + k1; // y[n][k1] over the pair's own two rows (R N1 <= 2 TS entries)
+#pragma unroll
+      for (int n = 0; n < R; n++)
+        yp[n * N1] = make_float2(xr[FFT_OUT(n)], xi[FFT_OUT(n)]);
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  W2_STAMP(2);
+
+  // ---------------- recombination over k1 + posterior: lanes = dy ----------------
+  const bioem_hip_param5 q = a.params[oc];
+  const float sumref = a.sumRef[p], sumsqref = a.sumsqRef[p];
+  double t2, prior;
+  logpro_consts(a.pd, q, t2, prior);
+  const float Np = a.pd.Ntotpi;
+  const double A = (double) (3 - Np) * 0.5;
+  const float nn = (float) (N * N);
+  LseF L;
+  L.m = -INFINITY;
+  L.s = 0.;
+  L.id = 0x7fffffff;
+  L.val = 0.f;
+  for (int c0 = 0; c0 < nd; c0 += 64)
+  {
+    const int wc = min(64, nd - c0);
+    const int G = 64 / wc;
+    const int g = lane / wc, dyl = lane - g * wc;
+    const bool act = g < G;
+    const int dyi = c0 + dyl;          // sorted index of this lane's dy
+    const int dy = (dyi - mD) * gs;    // pixels
+    const int res = ((dy % R) + R) % R;
+    const int step = dy < 0 ? dy + N : dy;
+    const int iyr = dinv[dyi];         // visiting rank
+    for (int pj = act ? g : npw; pj < npw; pj += G)
+    {
+      const int pair = pj0 + pj;
+      const float2 *yp = Tl + (size_t) (2 * pair) * TS + res * N1;
+      float2 y = yp[0];
+      float sr = y.x, si = y.y; // k1 = 0: twiddle 1
+      int idx = 0;
+#pragma unroll 4
+      for (int k1 = 1; k1 < N1; k1++)
+      {
+        idx += step;
+        if (idx >= N)
+          idx -= N;
+        const float2 w = twl[idx];
+        y = yp[k1];
+        sr = fmaf(y.x, w.x, sr);
+        sr = fmaf(-y.y, w.y, sr);
+        si = fmaf(y.x, w.y, si);
+        si = fmaf(y.y, w.x, si);
+      }
+#pragma unroll
+      for (int e = 0; e < 2; e++)
+      {
+        const int m = 2 * pair + e;
+        if (m < nd)
+        {
+          const float cc = (e ? si : sr) / nn;
+          // bioem_algorithm.h:32-36, float expression in the reference's order
+          const float firstele = Np * (sumsqref * q.sumsquareC - cc * cc) + 2 * sumref * q.sumC * cc -
+                                 sumsqref * q.sumC * q.sumC - sumref * sumref * q.sumsquareC;
+          double lp = A * log_of_float(firstele, ltab) + t2;
+          lp -= prior;
+          lsef_push(L, lp, dinv[m] * nd + iyr, cc, a.algo);
+        }
+      }
+    }
+  }
+  W2_STAMP(3);
+  lsef_wave_reduce(L);
+  if (lane == 0)
+    lsew[wave] = L;
+  __syncthreads();
+  W2_STAMP(4);
+  if (threadIdx.x == 0)
+  {
+    LseF Z = lsew[0];
+    for (int w = 1; w < 4; w++)
+    {
+      const LseF o = lsew[w];
+      if (o.m > Z.m || (o.m == Z.m && o.id < Z.id))
+      {
+        const double sc = (Z.m == -INFINITY) ? 0. : Z.s * exp_fast_nonpos((double) Z.m - (double) o.m);
+        Z.s = sc + o.s;
+        Z.m = o.m;
+        Z.id = o.id;
+        Z.val = o.val;
+      }
+      else
+      {
+        const double sc = (o.m == -INFINITY) ? 0. : o.s * exp_fast_nonpos((double) o.m - (double) Z.m);
+        Z.s += sc;
+      }
+    }
+    Partial r;
+    r.sumExp = Z.s;
+    r.best = Z.m;
+    r.id = Z.id;
+    r.value = Z.val;
+    r.pad = 0;
+    a.partials[(size_t) p * a.ldPart + oc] = r;
+  }
+}
+
+} // namespace
+
+#endif
