@@ -897,7 +897,11 @@ static int create_impl(bioem_hip_handle *out, int device, const bioem_hip_param_
     while (ts % 16 != 4)
       ts++;
     const int N1 = N / R;
-    if (nblk <= 2 && rpw <= (nblk == 1 ? 32 : 21) && N1 <= 32 && h->nd <= 128 && (!nyq || mD <= 42) &&
+    // measured against the tiled k_compare_wide (224^2): +-20 px (two 21-row tiles per axis) 15.9 vs 20.7 M/s, +-30 px
+    // (three tiles) 14.8 vs 9.6, +-40 px 12.5 vs 7.2; with a T block beyond 80 KiB only one block fits a CU (256^2
+    // +-40 px: 5.5 vs 6.2) -> this kernel from three tiles per axis on, while two blocks per CU fit
+    const bool pays = (h->nd > 42 && wide2_lds_bytes(N, R, rows2, ts) <= 80 * 1024) || getenv("BIOEM_FORCE_WIDE2");
+    if (pays && nblk <= 2 && rpw <= (nblk == 1 ? 32 : 21) && N1 <= 32 && h->nd <= 128 && (!nyq || mD <= 42) &&
         wide2_lds_bytes(N, R, rows2, ts) <= 160 * 1024)
     {
       h->wide2 = true;

@@ -305,6 +305,39 @@ def test_rccl_merge_single_rank_communicator():
     E2.close()
 
 
+def test_torch_rccl_merge_single_rank_process_group():
+    """bench.py's exchange step on the real backend: torch.distributed with backend "nccl" (= RCCL on ROCm), a
+    one-rank process group on the box's GPU, all_gather_into_tensor on device tensors inside merge_prob_maps --
+    map entries, orientation offset and the K-best candidates come back as the host merge delivers them."""
+    import socket
+    import torch
+    import torch.distributed as dist
+    import bioem_amd.engine as eng
+    from bioem_amd.dist_merge import merge_prob_maps
+    case, S = setup_for("g4_n32_angles")
+    K = S.pd.writeAngles
+    E = make_shard_engine(S, 1, 0, S.nAngles)
+    _, pmap = run_shard(E, 0, S.nAngles)
+    cands = E.topk_angles(K, orc.logp_constant(S.pd))
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1,
+                            device_id=torch.device("cuda", 0))
+    try:
+        merged, mc = merge_prob_maps(pmap, torch.device("cuda", 0), orient_offset=7, cands=cands)
+    finally:
+        dist.destroy_process_group()
+    want = pmap.copy()
+    want["orient"] += 7
+    assert merged.tobytes() == want.tobytes()
+    wc = cands.copy()
+    wc["orient"] = np.where(wc["orient"] >= 0, wc["orient"] + 7, wc["orient"])
+    assert mc.tobytes() == wc.tobytes()
+    E.close()
+
+
 def test_ctf_range_entry_and_split_merge():
     """bioem_hip_project_convolve_compare_ctf: the CTF grid split (used when there are fewer orientations than GPUs).
     Pieces (orientation block x CTF range) with private blocks, merged in serial visiting order == one run, map entries
@@ -733,6 +766,29 @@ def test_image_sizes_against_oracle(N, maxD, grid, fast, algo):
     W = Workload(N=N, nP=nP, nOrient=nO, nEnv=2, maxD=maxD, grid=grid, algo=algo, npts=300)
     try:
         assert W.engine.fast_path is bool(fast)
+        sel = list(range(nP))
+        want, const = oracle_on_workload(W, sel, nO, algo)
+        _, got = run_workload(W, 0, nO)
+        assert_workload_matches(got, want, const, sel)
+    finally:
+        W.engine.close()
+
+
+# k_compare_wide2 (shared column transforms + row FFT) is picked from three 21-row tiles per axis on; forced here for
+# every register-FFT length, one and two column blocks, the Nyquist split, row strides 1..3, odd and even row counts
+# per wave, windows from +-16 to +-41 px
+@pytest.mark.parametrize("N,maxD,grid", [(64, 20, 1), (128, 40, 1), (224, 20, 1), (224, 41, 1), (100, 40, 2), (96, 16, 1),
+                                         (256, 25, 1), (180, 20, 1), (250, 30, 1), (150, 16, 1), (44, 20, 1),
+                                         (60, 25, 1), (120, 22, 1), (90, 40, 2), (200, 33, 1), (36, 16, 1), (84, 30, 1),
+                                         (34, 16, 1), (128, 62, 2)])
+@pytest.mark.parametrize("algo", [1, 2])
+def test_wide2_kernel_against_oracle(N, maxD, grid, algo, monkeypatch):
+    from bioem_amd.synthetic import Workload
+    monkeypatch.setenv("BIOEM_FORCE_WIDE2", "1")
+    nP, nO = 5, 7                                   # 7 orientations x 2 CTFs x 5 particles
+    W = Workload(N=N, nP=nP, nOrient=nO, nEnv=2, maxD=maxD, grid=grid, algo=algo, npts=300)
+    try:
+        assert W.engine.kernel_name == "k_compare_wide2", W.engine.kernel_signature
         sel = list(range(nP))
         want, const = oracle_on_workload(W, sel, nO, algo)
         _, got = run_workload(W, 0, nO)
