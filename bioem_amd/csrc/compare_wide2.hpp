@@ -174,7 +174,15 @@ __global__ __launch_bounds__(256, 2) void k_compare_wide2(const CompareArgs a)
           }
           // next step of this wave: same block four k1 further, or the first one of the next column block
           primed = false;
-          if (k1 + 4 < N1)
+          // (measured at 224^2 +-40 px, same device: holding the next step's first rows across the round's barriers
+          // costs more in register spills than the hidden latency returns -- 35.7 vs 34.4 ms per launch)
+#ifndef BIOEM_W2_PRIME
+#define BIOEM_W2_PRIME 0
+#endif
+          if (!BIOEM_W2_PRIME)
+          {
+          }
+          else if (k1 + 4 < N1)
           {
             prime(k1 + 4, laneoff);
             primed = true;
@@ -201,26 +209,41 @@ __global__ __launch_bounds__(256, 2) void k_compare_wide2(const CompareArgs a)
           {
             const const_float2_ptr twk = as_constant(a.twk) + (size_t) k1s * nd;
             const float2 *ys = U + (size_t) s * R * 64 + lane;
-            float2 w[NRW], y[NRW];
+#ifndef BIOEM_W2_FOLD_CHUNK
+#define BIOEM_W2_FOLD_CHUNK 7
+#endif
+            // rows in chunks: a chunk's LDS reads are issued together, then its FMAs (the chunk size bounds the
+            // registers the reads occupy)
+            constexpr int FC = BIOEM_W2_FOLD_CHUNK;
 #pragma unroll
-            for (int d = 0; d < NRW; d++)
+            for (int d0 = 0; d0 < NRW; d0 += FC)
             {
-              const int m = min(r0 + d, nd - 1);
-              const int dx = (m - mD) * gs;
-              const int res = ((dx % R) + R) % R;
-              w[d] = make_float2(twk[m].x, twk[m].y);
-              y[d] = ys[res * 64];
-            }
+              float2 w[FC], y[FC];
 #pragma unroll
-            for (int d = 0; d < NRW; d++)
-            {
-              float tr = Tr[blk][d], ti = Ti[blk][d];
-              tr = fmaf(y[d].x, w[d].x, tr);
-              tr = fmaf(-y[d].y, w[d].y, tr);
-              ti = fmaf(y[d].x, w[d].y, ti);
-              ti = fmaf(y[d].y, w[d].x, ti);
-              Tr[blk][d] = tr;
-              Ti[blk][d] = ti;
+              for (int e = 0; e < FC; e++)
+              {
+                const int d = d0 + e;
+                const int m = min(r0 + d, nd - 1);
+                const int dx = (m - mD) * gs;
+                const int res = ((dx % R) + R) % R;
+                w[e] = make_float2(twk[m].x, twk[m].y);
+                y[e] = ys[res * 64];
+              }
+#pragma unroll
+              for (int e = 0; e < FC; e++)
+              {
+                const int d = d0 + e;
+                if (d < NRW)
+                {
+                  float tr = Tr[blk][d], ti = Ti[blk][d];
+                  tr = fmaf(y[e].x, w[e].x, tr);
+                  tr = fmaf(-y[e].y, w[e].y, tr);
+                  ti = fmaf(y[e].x, w[e].y, ti);
+                  ti = fmaf(y[e].y, w[e].x, ti);
+                  Tr[blk][d] = tr;
+                  Ti[blk][d] = ti;
+                }
+              }
             }
           }
         }

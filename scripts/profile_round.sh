@@ -28,5 +28,10 @@ rc=$?
 find $O -name "*_agent_info.csv" -delete
 # the per-dispatch traces of the counter passes are large; keep the counter files and the stats
 find $O/sqa $O/sqb $O/tc $O/fetch $O/write -name "*_kernel_trace.csv" -delete 2>/dev/null
+find $O/stats -name "*_kernel_trace.csv" -delete 2>/dev/null
+# counter files: only the rows of the comparison kernels travel back (gpurun merges at most 64 MiB)
+for f in $(find $O -name "*_counter_collection.csv"); do
+  (head -1 $f; grep k_compare $f) > $f.tmp && mv $f.tmp $f
+done
 ls -R $O | head -60
 exit $rc
