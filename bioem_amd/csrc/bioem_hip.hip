@@ -1669,11 +1669,17 @@ const char *rccl_load()
 {
   if (g_rccl.lib)
     return nullptr;
-  const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+  // a process must hold ONE copy of RCCL (a second one -- e.g. PyTorch's bundled librccl.so next to ROCm's -- ends in
+  // a double free at exit): take the copy that is already loaded, if any, before loading one by the name other
+  // libraries ask for
+  const char *names[] = {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"};
   void *lib = nullptr;
-  for (const char *n : names)
-    if ((lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL)))
+  for (const char *n : {"librccl.so.1", "librccl.so"})
+    if ((lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL | RTLD_NOLOAD)))
       break;
+  for (const char *n : names)
+    if (!lib)
+      lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
   if (!lib)
     return "librccl.so not found (needed for the multi-GPU merge)";
   g_rccl.CommInitAll = (decltype(g_rccl.CommInitAll)) dlsym(lib, "ncclCommInitAll");

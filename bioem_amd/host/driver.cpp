@@ -270,7 +270,8 @@ int Driver::configure(int ac, char **av)
     check(h, bioem_hip_upload_orientations(h, param.angles.data(), nA, param.doquater ? 1 : 0), "upload orientations");
   }
   // RCCL carries the merge when every shard has a GPU of its own
-  useRccl = nShards > 1 && nDevUsed == nShards && !splitCTF && !getenv("BIOEM_HOST_MERGE");
+  // (BIOEM_FORCE_RCCL=1: also with a single shard -- a one-rank communicator, to exercise this path on a one-GPU box)
+  useRccl = (nShards > 1 || getenv("BIOEM_FORCE_RCCL")) && nDevUsed == nShards && !splitCTF && !getenv("BIOEM_HOST_MERGE");
   return 0;
 }
 

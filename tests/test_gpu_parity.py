@@ -286,6 +286,7 @@ def test_rccl_merge_single_rank_communicator():
     device).  The box has one GPU, so the communicator has one rank: RCCL initialises, the collective runs on the
     engine's stream, the folded block and the K best orientations come back -- equal to what finish_run / topk_angles
     deliver.  Two handles on one device are refused (one GPU per shard)."""
+    import torch  # noqa: F401  (first, so that the process holds PyTorch's copy of RCCL and no second one)
     import bioem_amd.engine as eng
     case, S = setup_for("g4_n32_angles")
     K = S.pd.writeAngles
@@ -483,6 +484,33 @@ def test_cli_end_to_end_against_reference_outputs(name, shards, tmp_path):
                 for g, m in zip(ga[m_], ma[m_]):
                     assert g["angles"] == m["angles"] and abs(g["logp"] - m["logp"]) <= 5e-3
                     assert len(g["sep"]) == len(m["sep"])
+
+
+@pytest.mark.parametrize("name", ["g4_n32_angles", "g10_n64"])
+def test_cli_merges_over_rccl(name, tmp_path):
+    """The CLI's multi-GPU exchange step (bioem_hip_merge: RCCL all-gather + device fold + K-best candidates) with the
+    one-rank communicator a one-GPU box allows (BIOEM_FORCE_RCCL=1): outputs equal to the reference's files."""
+    exe = os.path.join(ROOT, "bioem_amd", "bin", "bioEM")
+    case, S = setup_for(name)
+    cmd = [exe, "--Inputfile", os.path.join(case["dir"], "param.txt"), "--OutputFile", "out.txt"] + \
+        write_case_inputs(case, tmp_path)
+    r = subprocess.run(cmd, cwd=str(tmp_path), env=dict(os.environ, BIOEM_GPUS="1", BIOEM_FORCE_RCCL="1",
+                                                        BIOEM_DEBUG_OUTPUT="1"),
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:]
+    assert "merge RCCL" in r.stdout
+    gold = iof.parse_output_probabilities(golden_output(case, 1))
+    mine = iof.parse_output_probabilities(open(tmp_path / "out.txt").read())
+    for g, m in zip(gold, mine):
+        assert abs(g["logp"] - m["logp"]) <= max(ABS_TOL, REL_TOL * abs(g["logp"]))
+        assert (g["angles"], g["ctf"], g["cx"], g["cy"]) == (m["angles"], m["ctf"], m["cx"], m["cy"])
+    if S.pd.writeAngles:
+        ga = iof.parse_ang_prob(os.path.join(case["dir"], "ANG_PROB_algo1"))
+        ma = iof.parse_ang_prob(str(tmp_path / "ANG_PROB"))
+        for m_ in ga:
+            assert [g["angles"] for g in ga[m_]] == [m["angles"] for m in ma[m_]]
+            for g, m in zip(ga[m_], ma[m_]):
+                assert abs(g["logp"] - m["logp"]) <= 5e-3
 
 
 def test_cli_accepts_the_reference_performance_knobs(tmp_path):
