@@ -1127,15 +1127,21 @@ static int create_impl(bioem_hip_handle *out, int device, const bioem_hip_param_
   }
 
   if (h->wide2)
-  { // recombination twiddles exp(2 pi i dx k1 / N) for the window rows in sorted order, dx = (m - mD) gs
-    std::vector<float2> t2((size_t) h->N1 * h->nd);
+  { // recombination twiddles exp(2 pi i dx k1 / N), dx = (m - mD) gs, laid out per (k1, wave): the NRW window rows a
+    // wave folds are contiguous (rows beyond the window: zero)
+    const int NRW = h->w2NRW, rpw = (h->nd + 3) / 4;
+    std::vector<float2> t2((size_t) h->N1 * 4 * NRW, make_float2(0.f, 0.f));
     for (int k1 = 0; k1 < h->N1; k1++)
-      for (int m = 0; m < h->nd; m++)
-      {
-        const long long dx = (long long) (m - mD) * h->gs;
-        const double ang = 2.0 * M_PI * (double) (((dx * k1) % N + N) % N) / (double) N;
-        t2[(size_t) k1 * h->nd + m] = make_float2((float) cos(ang), (float) sin(ang));
-      }
+      for (int w = 0; w < 4; w++)
+        for (int d = 0; d < NRW; d++)
+        {
+          const int m = w * rpw + d;
+          if (m >= h->nd)
+            continue;
+          const long long dx = (long long) (m - mD) * h->gs;
+          const double ang = 2.0 * M_PI * (double) (((dx * k1) % N + N) % N) / (double) N;
+          t2[((size_t) k1 * 4 + w) * NRW + d] = make_float2((float) cos(ang), (float) sin(ang));
+        }
     HIP_CHECK(h, hipMalloc(&h->dTwk2, sizeof(float2) * t2.size()));
     HIP_CHECK(h, hipMemcpy(h->dTwk2, t2.data(), sizeof(float2) * t2.size(), hipMemcpyHostToDevice));
   }
@@ -1906,7 +1912,7 @@ int bioem_hip_reset_kernel_stats(bioem_hip_handle h)
 // diagnostic build only: summed shader cycles per phase of k_compare_wide2 (and reset)
 int bioem_hip_debug_w2_stamps(unsigned long long *out8)
 {
-  unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long z[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   if (hipDeviceSynchronize() != hipSuccess || hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_w2_stamps), sizeof(z)) != hipSuccess)
     return 1;
   return hipMemcpyToSymbol(HIP_SYMBOL(g_w2_stamps), z, sizeof(z)) == hipSuccess ? 0 : 1;

@@ -34,7 +34,7 @@ namespace
 // ------------------------------------------------------------------------------------------------
 // diagnostic build only (-DBIOEM_W2_STAMPS, never shipped): shader-clock cycles per phase of wave 0, summed over blocks
 #ifdef BIOEM_W2_STAMPS
-__device__ unsigned long long g_w2_stamps[8];
+__device__ unsigned long long g_w2_stamps[16];
 #define W2_STAMP(k)                                                                                                \
   do                                                                                                               \
   {                                                                                                                \
@@ -100,10 +100,15 @@ __global__ __launch_bounds__(256, 2) void k_compare_wide2(const CompareArgs a)
     p = c * a.pchunk + (rem - oc * pc);
   }
   const size_t M = (size_t) N * H;
+  // timing-only ablation builds (never shipped): zero-record descriptors drop the operand traffic, the instruction
+  // stream and waits stay
+#ifndef BIOEM_W2_ABLATE
+#define BIOEM_W2_ABLATE 0
+#endif
   const auto rsrcF = __builtin_amdgcn_make_buffer_rsrc(const_cast<float2 *>(a.ref + (size_t) p * M), 0,
-                                                       (int) (M * sizeof(float2)), 0x00020000);
+                                                       BIOEM_W2_ABLATE ? 0 : (int) (M * sizeof(float2)), 0x00020000);
   const auto rsrcC = __builtin_amdgcn_make_buffer_rsrc(const_cast<float2 *>(a.conv + (size_t) oc * M), 0,
-                                                       (int) (M * sizeof(float2)), 0x00020000);
+                                                       BIOEM_W2_ABLATE ? 0 : (int) (M * sizeof(float2)), 0x00020000);
 
 #ifdef BIOEM_W2_STAMPS
   unsigned long long stamp_ = __builtin_amdgcn_s_memtime();
@@ -124,17 +129,27 @@ __global__ __launch_bounds__(256, 2) void k_compare_wide2(const CompareArgs a)
       Ti[b][d] = 0.f;
     }
   __syncthreads();
-  // operand ring of this wave's steps (blk, k1 = base + wave): the first RD row pairs of the NEXT step are issued
-  // before the round's barriers, so they fly while the round's slots are folded
-  u32x4 rf[RD], rc[RD];
-  bool primed = false;
-  auto prime = [&](int k1n, unsigned laneoffn) {
+  // LDS position (float2 units, lane included) of window row d's residue row inside a slot
+  int yoff[NRW];
 #pragma unroll
-    for (int t = 0; t < RD; t++)
-    {
-      rf[t] = __builtin_amdgcn_raw_buffer_load_b128(rsrcF, laneoffn, (unsigned) (k1n * R2 + t) * rowbytes, 0);
-      rc[t] = __builtin_amdgcn_raw_buffer_load_b128(rsrcC, laneoffn, (unsigned) (k1n * R2 + t) * rowbytes, 0);
-    }
+  for (int d = 0; d < NRW; d++)
+  {
+    const int m = min(r0 + d, nd - 1);
+    const int dx = (m - mD) * gs;
+    yoff[d] = (((dx % R) + R) % R) * 64 + lane;
+  }
+  // particle row pairs of this wave's NEXT step may be requested as soon as the current step's outputs are parked
+  // (BIOEM_W2_FNEXT; measured: -1.6 %, and the kernel without ANY operand traffic -- zero-record descriptors -- is only
+  // 3 % faster: operand delivery is not what the time goes to, so the registers are spent elsewhere)
+#ifndef BIOEM_W2_FNEXT
+#define BIOEM_W2_FNEXT 0
+#endif
+  u32x4 fx[R2];
+  bool fready = false;
+  auto request_f = [&](int k1n, unsigned laneoffn) {
+#pragma unroll
+    for (int t = 0; t < R2; t++)
+      fx[t] = __builtin_amdgcn_raw_buffer_load_b128(rsrcF, laneoffn, (unsigned) (k1n * R2 + t) * rowbytes, 0);
   };
 #pragma unroll
   for (int blk = 0; blk < NBLK; blk++)
@@ -151,64 +166,68 @@ __global__ __launch_bounds__(256, 2) void k_compare_wide2(const CompareArgs a)
         if (k1 < N1)
         { // this wave's step of the round: product + register FFT, outputs to slot `wave`
           float xr[R], xi[R];
-          if (!primed)
-            prime(k1, laneoff);
+          // operands of the step: ALL R/2 particle row pairs are requested at once -- they land in the registers the
+          // FFT inputs take over (a row pair of F is consumed exactly when its two products are formed), the conv
+          // row pairs follow through a ring
+#ifndef BIOEM_W2_CRING
+#define BIOEM_W2_CRING 4
+#endif
+          constexpr int RC = (R2 % BIOEM_W2_CRING == 0) ? BIOEM_W2_CRING : RD;
+          u32x4 rc[RC];
+          if (!fready)
+            request_f(k1, laneoff);
+#pragma unroll
+          for (int t = 0; t < RC; t++)
+            rc[t] = __builtin_amdgcn_raw_buffer_load_b128(rsrcC, laneoff, (unsigned) (k1 * R2 + t) * rowbytes, 0);
 #pragma unroll
           for (int k2p = 0; k2p < R2; k2p++)
           {
-            const float4 f = as_float4(rf[k2p % RD]);
-            const float4 c = as_float4(rc[k2p % RD]);
+            const float4 f = as_float4(fx[k2p]);
+            const float4 c = as_float4(rc[k2p % RC]);
             // X = conv * conj(ref)   (bioem.cpp:1452-1455)
             xr[FFT_IN(2 * k2p)] = fmaf(c.x, f.x, c.y * f.y);
             xi[FFT_IN(2 * k2p)] = fmaf(c.y, f.x, -(c.x * f.y));
             xr[FFT_IN(2 * k2p + 1)] = fmaf(c.z, f.z, c.w * f.w);
             xi[FFT_IN(2 * k2p + 1)] = fmaf(c.w, f.z, -(c.z * f.w));
-            if (k2p + RD < R2)
-            {
-              rf[k2p % RD] = __builtin_amdgcn_raw_buffer_load_b128(rsrcF, laneoff,
-                                                                  (unsigned) (k1 * R2 + k2p + RD) * rowbytes, 0);
-              rc[k2p % RD] = __builtin_amdgcn_raw_buffer_load_b128(rsrcC, laneoff,
-                                                                  (unsigned) (k1 * R2 + k2p + RD) * rowbytes, 0);
-            }
+            if (k2p + RC < R2)
+              rc[k2p % RC] = __builtin_amdgcn_raw_buffer_load_b128(rsrcC, laneoff,
+                                                                  (unsigned) (k1 * R2 + k2p + RC) * rowbytes, 0);
             __builtin_amdgcn_sched_barrier(0);
           }
-          // next step of this wave: same block four k1 further, or the first one of the next column block
-          primed = false;
-          // (measured at 224^2 +-40 px, same device: holding the next step's first rows across the round's barriers
-          // costs more in register spills than the hidden latency returns -- 35.7 vs 34.4 ms per launch)
-#ifndef BIOEM_W2_PRIME
-#define BIOEM_W2_PRIME 0
-#endif
-          if (!BIOEM_W2_PRIME)
-          {
-          }
-          else if (k1 + 4 < N1)
-          {
-            prime(k1 + 4, laneoff);
-            primed = true;
-          }
-          else if (blk + 1 < nblk && wave < N1)
-          {
-            prime(wave, laneoff_next);
-            primed = true;
-          }
+          W2_STAMP(8);
           FFT_RUN(xr, xi);
+          W2_STAMP(9);
           float2 *slot = U + (size_t) wave * R * 64 + lane;
 #pragma unroll
           for (int n = 0; n < R; n++)
             slot[n * 64] = make_float2(xr[FFT_OUT(n)], xi[FFT_OUT(n)]);
+          // next step of this wave: same block four k1 further, or the first one of the next column block
+          fready = false;
+          if (BIOEM_W2_FNEXT && k1 + 4 < N1)
+          {
+            request_f(k1 + 4, laneoff);
+            fready = true;
+          }
+          else if (BIOEM_W2_FNEXT && blk + 1 < nblk && wave < N1)
+          {
+            request_f(wave, laneoff_next);
+            fready = true;
+          }
+          W2_STAMP(10);
         }
         __syncthreads();
         W2_STAMP(5);
         // fold the round's slots into this wave's rows:  T[dx] += w_N^(dx k1) * y_k1[dx mod R]
-        // (all NRW accumulators, rows beyond this wave's share clamped to its last row and never stored)
+        // (all NRW accumulators; rows beyond this wave's share fold zeros and are never stored)
+#pragma unroll
         for (int s = 0; s < 4; s++)
         {
           const int k1s = base + s;
           if (k1s < N1)
           {
-            const const_float2_ptr twk = as_constant(a.twk) + (size_t) k1s * nd;
-            const float2 *ys = U + (size_t) s * R * 64 + lane;
+            // this wave's NRW twiddles of step k1s are contiguous: a few wide scalar loads
+            const const_float2_ptr twk = as_constant(a.twk) + ((size_t) k1s * 4 + wave) * NRW;
+            const float2 *ys = U + (size_t) s * R * 64;
 #ifndef BIOEM_W2_FOLD_CHUNK
 #define BIOEM_W2_FOLD_CHUNK 7
 #endif
@@ -222,12 +241,9 @@ __global__ __launch_bounds__(256, 2) void k_compare_wide2(const CompareArgs a)
 #pragma unroll
               for (int e = 0; e < FC; e++)
               {
-                const int d = d0 + e;
-                const int m = min(r0 + d, nd - 1);
-                const int dx = (m - mD) * gs;
-                const int res = ((dx % R) + R) % R;
-                w[e] = make_float2(twk[m].x, twk[m].y);
-                y[e] = ys[res * 64];
+                const int d = d0 + e < NRW ? d0 + e : NRW - 1;
+                w[e] = make_float2(twk[d].x, twk[d].y);
+                y[e] = ys[yoff[d]];
               }
 #pragma unroll
               for (int e = 0; e < FC; e++)

@@ -13,7 +13,7 @@ maxd = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 W = Workload(N=224, nP=1000, nOrient=32, nEnv=4, nDefocus=8, maxD=maxd)
 E = W.engine
 L = eng.load_library()
-out = (C.c_ulonglong * 8)()
+out = (C.c_ulonglong * 16)()
 for it in range(2):
     raw, pmap, _ = eng.new_prob_block(W.nP, W.nOrient, 0)
     E.start_run(raw)
@@ -22,9 +22,10 @@ for it in range(2):
     L.bioem_hip_debug_w2_stamps(out)
 v = [int(x) for x in out]
 n = W.nOrient * W.nCTF * W.nP
-names = ["column pass total (incl. 5+6)", "T -> LDS", "row FFT", "recombination + posterior", "wave reduce + barrier",
-         "  column: produce + barrier", "  column: fold + barrier", "-"]
-tot = v[0] + v[1] + v[2] + v[3] + v[4]
+names = ["column pass: tail", "T -> LDS + barrier", "row FFT", "recombination + posterior", "wave reduce + barrier",
+         "column: barrier after produce", "column: fold + barrier", "-", "column: loads + spectrum product",
+         "column: register FFT", "column: park outputs, request next F"]
+tot = sum(v[:11])
 print(E.kernel_signature, "comparisons", n)
-for k in range(7):
+for k in (8, 9, 10, 5, 6, 0, 1, 2, 3, 4):
     print("%-34s %8.0f cycles/comparison  %5.1f %%" % (names[k], v[k] / n, 100.0 * v[k] / tot))
