@@ -247,3 +247,29 @@ def test_multiple_mrc_reader_delivers_the_golden_maps(tmp_path):
         os.chdir(cwd)
     assert maps.shape == case["maps"].shape
     assert np.allclose(maps, case["maps"], rtol=0, atol=2e-6)
+
+
+def test_bench_starts_its_own_ranks_without_a_launcher():
+    """`python bench.py --gpus 2` with no WORLD_SIZE in the environment: the parent (which never touches a GPU) must
+    start two child ranks with the launcher contract's variables and hand rank 0's exit code through.  Here, without
+    a GPU, both ranks stop at the device check -- which proves they were started as ranks 0 and 1 of a world of 2."""
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
+                        "--no-cpu-baseline"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
+                       timeout=300)
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("needs a box without a GPU (the GPU suite runs bench.py itself)")
+    assert r.returncode == 2 and r.stdout.strip() == ""
+    assert r.stderr.count("bench.py needs a GPU") == 2          # one line per self-started rank
+    assert "WORLD_SIZE" not in r.stderr                         # no rank saw a world size other than --gpus
+
+
+def test_cpu_share_detection():
+    """The CPU baseline runs one thread per CPU the cgroup grants (cpu.max quota / period), not per visible core."""
+    lim = orc.cgroup_cpu_limit()
+    assert lim is None or lim >= 1
+    n = orc.usable_cpus(cap=1 << 20)
+    assert 1 <= n <= (os.cpu_count() or 1) and (lim is None or n <= lim)
