@@ -362,6 +362,12 @@ fast_kernel_t wide2_kernel_r(int nblk, bool nyq)
   }
   return nblk == 1 ? k_compare_wide2<R, 32, 1, false> : k_compare_wide2<R, 21, 2, false>;
 }
+// windows of 32..44 rows (at most 11 per wave) over two column blocks with 16- or 8-point register FFTs: 44 T
+// accumulators + a short FFT fit three waves per SIMD, the T block (<= 40 KiB) three blocks per CU
+fast_kernel_t wide2_kernel_small(int R)
+{
+  return R == 8 ? k_compare_wide2<8, 11, 2, false> : k_compare_wide2<16, 11, 2, false>;
+}
 fast_kernel_t wide2_kernel(int R, int nblk, bool nyq)
 {
   switch (R)
@@ -476,8 +482,8 @@ int launch_compare_fold(bioem_hip_ctx *h, const BatchBuf &bb, int nOC, int orien
         hipLaunchKernelGGL(k_nyquist_rows<42>, gridq, dim3(256), 0, h->stream, aw);
     }
     const size_t lds = wide2_lds_bytes(h->N, 2 * h->fast, h->w2Rows2, h->w2TS);
-    hipLaunchKernelGGL(wide2_kernel(2 * h->fast, h->w2NBLK, h->nyq), dim3((unsigned) ((size_t) nOC * h->nMaps)), dim3(256),
-                       lds, h->stream, aw);
+    hipLaunchKernelGGL(h->w2NRW == 11 ? wide2_kernel_small(2 * h->fast) : wide2_kernel(2 * h->fast, h->w2NBLK, h->nyq),
+                       dim3((unsigned) ((size_t) nOC * h->nMaps)), dim3(256), lds, h->stream, aw);
   }
   else if (h->fast || h->rowsK)
   {
@@ -876,7 +882,8 @@ static int create_impl(bioem_hip_handle *out, int device, const bioem_hip_param_
   // wide windows, first choice: k_compare_wide2 (one launch per batch, shared column transforms, row FFT).  Needs an
   // even image size with at most two 64-column blocks, at most 32 (one block) / 21 (two blocks) window rows per wave,
   // and its T block [rows][H] in LDS
-  if (N % 2 == 0 && N >= 8 && (mD > 15 || h->nd > 31) && h->nd == 2 * mD + 1 && !getenv("BIOEM_NO_WIDE2"))
+  if (N % 2 == 0 && N >= 8 && (mD > 15 || h->nd > 31 || (getenv("BIOEM_FORCE_WIDE2") && h->nd >= 21)) &&
+      h->nd == 2 * mD + 1 && !getenv("BIOEM_NO_WIDE2"))
   {
     int R = (N % 32 == 0) ? 32 : (N % 16 == 0) ? 16 : (N % 8 == 0) ? 8 : (N % 4 == 0) ? 4 : 2;
     if (R < 8 && !getenv("BIOEM_POW2_FFT"))
@@ -892,6 +899,11 @@ static int create_impl(bioem_hip_handle *out, int device, const bioem_hip_param_
     const bool nyq = BIOEM_NYQUIST_SPLIT && (N / 2) % 64 == 0;
     const int nblk = nyq ? (h->H - 1) / 64 : (h->H + 63) / 64;
     const int rpw = (h->nd + 3) / 4;
+    // small variant (see wide2_kernel_small): measured at 224^2 against the tiled kernel / the 31-row template:
+    // +-20 px 24.3 vs 20.7 M/s, +-15 px 32.8 vs 31.7, +-12 px 33.5 vs 34.6 -> used beyond 31 rows
+    const bool small = nblk == 2 && rpw <= 11 && !nyq && (R == 32 || R == 16 || R == 8) && !getenv("BIOEM_NO_WIDE2_SMALL");
+    if (small && R == 32)
+      R = 16;
     const int rows2 = 2 * ((h->nd + 1) / 2);
     int ts = h->H; // row stride = 4 mod 16 float2: the (row pair, k1) lanes of the row pass spread over the banks
     while (ts % 16 != 4)
@@ -900,7 +912,8 @@ static int create_impl(bioem_hip_handle *out, int device, const bioem_hip_param_
     // measured against the tiled k_compare_wide (224^2): +-20 px (two 21-row tiles per axis) 15.9 vs 20.7 M/s, +-30 px
     // (three tiles) 14.8 vs 9.6, +-40 px 12.5 vs 7.2; with a T block beyond 80 KiB only one block fits a CU (256^2
     // +-40 px: 5.5 vs 6.2) -> this kernel from three tiles per axis on, while two blocks per CU fit
-    const bool pays = (h->nd > 42 && wide2_lds_bytes(N, R, rows2, ts) <= 80 * 1024) || getenv("BIOEM_FORCE_WIDE2");
+    const bool pays = ((h->nd > 42 || (small && h->nd > 31)) && wide2_lds_bytes(N, R, rows2, ts) <= 80 * 1024) ||
+                      getenv("BIOEM_FORCE_WIDE2");
     if (pays && nblk <= 2 && rpw <= (nblk == 1 ? 32 : 21) && N1 <= 32 && h->nd <= 128 && (!nyq || mD <= 42) &&
         wide2_lds_bytes(N, R, rows2, ts) <= 160 * 1024)
     {
@@ -910,12 +923,15 @@ static int create_impl(bioem_hip_handle *out, int device, const bioem_hip_param_
       h->nyq = nyq;
       h->w2NBLK = nblk;
       h->w2NRW = nblk == 1 ? 32 : 21;
+      if (small)
+        h->w2NRW = 11;
       h->w2TS = ts;
       h->w2Rows2 = rows2;
       h->nyqWD = mD <= 20 ? 20 : mD <= 31 ? 31 : 42;
       if (nyq)
         h->winD = h->nyqWD; // sizes the Nyquist pre-kernel's tables
-      HIP_CHECK(h, hipFuncSetAttribute(reinterpret_cast<const void *>(wide2_kernel(R, nblk, nyq)),
+      HIP_CHECK(h, hipFuncSetAttribute(reinterpret_cast<const void *>(h->w2NRW == 11 ? wide2_kernel_small(R)
+                                                                                      : wide2_kernel(R, nblk, nyq)),
                                        hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int) wide2_lds_bytes(N, R, rows2, ts)));
     }

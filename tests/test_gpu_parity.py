@@ -808,7 +808,10 @@ def test_image_sizes_against_oracle(N, maxD, grid, fast, algo):
 @pytest.mark.parametrize("N,maxD,grid", [(64, 20, 1), (128, 40, 1), (224, 20, 1), (224, 41, 1), (100, 40, 2), (96, 16, 1),
                                          (256, 25, 1), (180, 20, 1), (250, 30, 1), (150, 16, 1), (44, 20, 1),
                                          (60, 25, 1), (120, 22, 1), (90, 40, 2), (200, 33, 1), (36, 16, 1), (84, 30, 1),
-                                         (34, 16, 1), (128, 62, 2)])
+                                         (34, 16, 1), (128, 62, 2),
+                                         # three waves per SIMD variant (<= 11 rows per wave, two column blocks, R 16 / 8)
+                                         (240, 18, 1), (200, 20, 1), (160, 17, 1), (224, 12, 1), (224, 21, 1),
+                                         (208, 44, 2)])
 @pytest.mark.parametrize("algo", [1, 2])
 def test_wide2_kernel_against_oracle(N, maxD, grid, algo, monkeypatch):
     from bioem_amd.synthetic import Workload
