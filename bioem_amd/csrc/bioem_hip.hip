@@ -362,10 +362,12 @@ fast_kernel_t wide2_kernel_r(int nblk, bool nyq)
   }
   return nblk == 1 ? k_compare_wide2<R, 32, 1, false> : k_compare_wide2<R, 21, 2, false>;
 }
-// windows of 32..44 rows (at most 11 per wave) over two column blocks with 16- or 8-point register FFTs: 44 T
-// accumulators + a short FFT fit three waves per SIMD, the T block (<= 40 KiB) three blocks per CU
-fast_kernel_t wide2_kernel_small(int R)
+// windows of 32..52 rows (at most 11 / 13 per wave) over two column blocks with 16- or 8-point register FFTs: 44 / 52 T
+// accumulators + a short FFT fit three waves per SIMD, the T block (<= 48 KiB) three blocks per CU
+fast_kernel_t wide2_kernel_small(int R, int nrw)
 {
+  if (nrw == 13)
+    return R == 8 ? k_compare_wide2<8, 13, 2, false> : k_compare_wide2<16, 13, 2, false>;
   return R == 8 ? k_compare_wide2<8, 11, 2, false> : k_compare_wide2<16, 11, 2, false>;
 }
 fast_kernel_t wide2_kernel(int R, int nblk, bool nyq)
@@ -482,7 +484,8 @@ int launch_compare_fold(bioem_hip_ctx *h, const BatchBuf &bb, int nOC, int orien
         hipLaunchKernelGGL(k_nyquist_rows<42>, gridq, dim3(256), 0, h->stream, aw);
     }
     const size_t lds = wide2_lds_bytes(h->N, 2 * h->fast, h->w2Rows2, h->w2TS);
-    hipLaunchKernelGGL(h->w2NRW == 11 ? wide2_kernel_small(2 * h->fast) : wide2_kernel(2 * h->fast, h->w2NBLK, h->nyq),
+    hipLaunchKernelGGL(h->w2NRW <= 13 ? wide2_kernel_small(2 * h->fast, h->w2NRW)
+                                      : wide2_kernel(2 * h->fast, h->w2NBLK, h->nyq),
                        dim3((unsigned) ((size_t) nOC * h->nMaps)), dim3(256), lds, h->stream, aw);
   }
   else if (h->fast || h->rowsK)
@@ -899,9 +902,10 @@ static int create_impl(bioem_hip_handle *out, int device, const bioem_hip_param_
     const bool nyq = BIOEM_NYQUIST_SPLIT && (N / 2) % 64 == 0;
     const int nblk = nyq ? (h->H - 1) / 64 : (h->H + 63) / 64;
     const int rpw = (h->nd + 3) / 4;
-    // small variant (see wide2_kernel_small): measured at 224^2 against the tiled kernel / the 31-row template:
-    // +-20 px 24.3 vs 20.7 M/s, +-15 px 32.8 vs 31.7, +-12 px 33.5 vs 34.6 -> used beyond 31 rows
-    const bool small = nblk == 2 && rpw <= 11 && !nyq && (R == 32 || R == 16 || R == 8) && !getenv("BIOEM_NO_WIDE2_SMALL");
+    // small variant (see wide2_kernel_small): measured at 224^2 against the tiled kernel / the 31-row template / the
+    // two-wave instantiation: +-20 px 24.3 vs 20.7 M/s, +-24 px 22.7 vs 17.7, +-15 px 32.8 vs 31.7, +-12 px 33.5 vs 34.6
+    // -> used from 32 rows on
+    const bool small = nblk == 2 && rpw <= 13 && !nyq && (R == 32 || R == 16 || R == 8) && !getenv("BIOEM_NO_WIDE2_SMALL");
     if (small && R == 32)
       R = 16;
     const int rows2 = 2 * ((h->nd + 1) / 2);
@@ -924,13 +928,13 @@ static int create_impl(bioem_hip_handle *out, int device, const bioem_hip_param_
       h->w2NBLK = nblk;
       h->w2NRW = nblk == 1 ? 32 : 21;
       if (small)
-        h->w2NRW = 11;
+        h->w2NRW = rpw <= 11 ? 11 : 13;
       h->w2TS = ts;
       h->w2Rows2 = rows2;
       h->nyqWD = mD <= 20 ? 20 : mD <= 31 ? 31 : 42;
       if (nyq)
         h->winD = h->nyqWD; // sizes the Nyquist pre-kernel's tables
-      HIP_CHECK(h, hipFuncSetAttribute(reinterpret_cast<const void *>(h->w2NRW == 11 ? wide2_kernel_small(R)
+      HIP_CHECK(h, hipFuncSetAttribute(reinterpret_cast<const void *>(h->w2NRW <= 13 ? wide2_kernel_small(R, h->w2NRW)
                                                                                       : wide2_kernel(R, nblk, nyq)),
                                        hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int) wide2_lds_bytes(N, R, rows2, ts)));
