@@ -364,6 +364,14 @@ fast_kernel_t wide2_kernel_r(int nblk, bool nyq)
 }
 // windows of 32..52 rows (at most 11 / 13 per wave) over two column blocks with 16- or 8-point register FFTs: 44 / 52 T
 // accumulators + a short FFT fit three waves per SIMD, the T block (<= 48 KiB) three blocks per CU
+// one column block (N <= 126, or 128 with the Nyquist split), at most 21 rows per wave, 16- / 8-point FFTs: 42 T
+// accumulators -> three waves per SIMD as well
+fast_kernel_t wide2_kernel_small1(int R, bool nyq)
+{
+  if (nyq)
+    return k_compare_wide2<16, 21, 1, true>;
+  return R == 8 ? k_compare_wide2<8, 21, 1, false> : k_compare_wide2<16, 21, 1, false>;
+}
 fast_kernel_t wide2_kernel_small(int R, int nrw)
 {
   if (nrw == 13)
@@ -484,8 +492,9 @@ int launch_compare_fold(bioem_hip_ctx *h, const BatchBuf &bb, int nOC, int orien
         hipLaunchKernelGGL(k_nyquist_rows<42>, gridq, dim3(256), 0, h->stream, aw);
     }
     const size_t lds = wide2_lds_bytes(h->N, 2 * h->fast, h->w2Rows2, h->w2TS);
-    hipLaunchKernelGGL(h->w2NRW <= 13 ? wide2_kernel_small(2 * h->fast, h->w2NRW)
-                                      : wide2_kernel(2 * h->fast, h->w2NBLK, h->nyq),
+    hipLaunchKernelGGL(h->w2NBLK == 1 && h->w2NRW == 21 ? wide2_kernel_small1(2 * h->fast, h->nyq)
+                       : h->w2NRW <= 13                 ? wide2_kernel_small(2 * h->fast, h->w2NRW)
+                                                        : wide2_kernel(2 * h->fast, h->w2NBLK, h->nyq),
                        dim3((unsigned) ((size_t) nOC * h->nMaps)), dim3(256), lds, h->stream, aw);
   }
   else if (h->fast || h->rowsK)
@@ -906,7 +915,10 @@ static int create_impl(bioem_hip_handle *out, int device, const bioem_hip_param_
     // two-wave instantiation: +-20 px 24.3 vs 20.7 M/s, +-24 px 22.7 vs 17.7, +-15 px 32.8 vs 31.7, +-12 px 33.5 vs 34.6
     // -> used from 32 rows on
     const bool small = nblk == 2 && rpw <= 13 && !nyq && (R == 32 || R == 16 || R == 8) && !getenv("BIOEM_NO_WIDE2_SMALL");
-    if (small && R == 32)
+    // the same for one column block (measured: 128^2 +-40 px 21.1 -> 23.3, +-30 px 27.8 -> 38.6, 120^2 +-25 px 29.2 -> 38.6)
+    const bool small1 = nblk == 1 && rpw <= 21 && (R == 32 || ((R == 16 || R == 8) && !nyq)) &&
+                        !getenv("BIOEM_NO_WIDE2_SMALL");
+    if ((small || small1) && R == 32)
       R = 16;
     const int rows2 = 2 * ((h->nd + 1) / 2);
     int ts = h->H; // row stride = 4 mod 16 float2: the (row pair, k1) lanes of the row pass spread over the banks
@@ -916,7 +928,8 @@ static int create_impl(bioem_hip_handle *out, int device, const bioem_hip_param_
     // measured against the tiled k_compare_wide (224^2): +-20 px (two 21-row tiles per axis) 15.9 vs 20.7 M/s, +-30 px
     // (three tiles) 14.8 vs 9.6, +-40 px 12.5 vs 7.2; with a T block beyond 80 KiB only one block fits a CU (256^2
     // +-40 px: 5.5 vs 6.2) -> this kernel from three tiles per axis on, while two blocks per CU fit
-    const bool pays = ((h->nd > 42 || (small && h->nd > 31)) && wide2_lds_bytes(N, R, rows2, ts) <= 80 * 1024) ||
+    const bool pays = ((h->nd > 42 || ((small || small1) && h->nd > 31)) &&
+                       wide2_lds_bytes(N, R, rows2, ts) <= 80 * 1024) ||
                       getenv("BIOEM_FORCE_WIDE2");
     if (pays && nblk <= 2 && rpw <= (nblk == 1 ? 32 : 21) && N1 <= 32 && h->nd <= 128 && (!nyq || mD <= 42) &&
         wide2_lds_bytes(N, R, rows2, ts) <= 160 * 1024)
@@ -929,12 +942,15 @@ static int create_impl(bioem_hip_handle *out, int device, const bioem_hip_param_
       h->w2NRW = nblk == 1 ? 32 : 21;
       if (small)
         h->w2NRW = rpw <= 11 ? 11 : 13;
+      if (small1)
+        h->w2NRW = 21;
       h->w2TS = ts;
       h->w2Rows2 = rows2;
       h->nyqWD = mD <= 20 ? 20 : mD <= 31 ? 31 : 42;
       if (nyq)
         h->winD = h->nyqWD; // sizes the Nyquist pre-kernel's tables
-      HIP_CHECK(h, hipFuncSetAttribute(reinterpret_cast<const void *>(h->w2NRW <= 13 ? wide2_kernel_small(R, h->w2NRW)
+      HIP_CHECK(h, hipFuncSetAttribute(reinterpret_cast<const void *>(small1            ? wide2_kernel_small1(R, nyq)
+                                                                     : h->w2NRW <= 13 ? wide2_kernel_small(R, h->w2NRW)
                                                                                       : wide2_kernel(R, nblk, nyq)),
                                        hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int) wide2_lds_bytes(N, R, rows2, ts)));

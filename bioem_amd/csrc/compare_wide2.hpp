@@ -56,7 +56,7 @@ __device__ __forceinline__ const_float2_ptr as_constant(const float2 *p)
 }
 
 template <int R, int NRW, int NBLK, bool NYQ>
-__global__ __launch_bounds__(256, (NRW <= 13 && R <= 16) ? 3 : 2) void k_compare_wide2(const CompareArgs a)
+__global__ __launch_bounds__(256, (NRW * NBLK <= 26 && R <= 16) ? 3 : 2) void k_compare_wide2(const CompareArgs a)
 {
   constexpr int R2 = R / 2;
   // depth of the operand ring (divides R2): the first RD row pairs of a wave's next step are issued before the
