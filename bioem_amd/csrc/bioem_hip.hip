@@ -372,8 +372,10 @@ fast_kernel_t wide2_kernel_small1(int R, bool nyq)
     return k_compare_wide2<16, 21, 1, true>;
   return R == 8 ? k_compare_wide2<8, 21, 1, false> : k_compare_wide2<16, 21, 1, false>;
 }
-fast_kernel_t wide2_kernel_small(int R, int nrw)
+fast_kernel_t wide2_kernel_small(int R, int nrw, bool nyq)
 {
+  if (nyq) // N/2 a multiple of 64 (256^2): R = 16 by choice
+    return nrw == 13 ? k_compare_wide2<16, 13, 2, true> : k_compare_wide2<16, 11, 2, true>;
   if (nrw == 13)
     return R == 8 ? k_compare_wide2<8, 13, 2, false> : k_compare_wide2<16, 13, 2, false>;
   return R == 8 ? k_compare_wide2<8, 11, 2, false> : k_compare_wide2<16, 11, 2, false>;
@@ -493,7 +495,7 @@ int launch_compare_fold(bioem_hip_ctx *h, const BatchBuf &bb, int nOC, int orien
     }
     const size_t lds = wide2_lds_bytes(h->N, 2 * h->fast, h->w2Rows2, h->w2TS);
     hipLaunchKernelGGL(h->w2NBLK == 1 && h->w2NRW == 21 ? wide2_kernel_small1(2 * h->fast, h->nyq)
-                       : h->w2NRW <= 13                 ? wide2_kernel_small(2 * h->fast, h->w2NRW)
+                       : h->w2NRW <= 13                 ? wide2_kernel_small(2 * h->fast, h->w2NRW, h->nyq)
                                                         : wide2_kernel(2 * h->fast, h->w2NBLK, h->nyq),
                        dim3((unsigned) ((size_t) nOC * h->nMaps)), dim3(256), lds, h->stream, aw);
   }
@@ -911,19 +913,22 @@ static int create_impl(bioem_hip_handle *out, int device, const bioem_hip_param_
     const bool nyq = BIOEM_NYQUIST_SPLIT && (N / 2) % 64 == 0;
     const int nblk = nyq ? (h->H - 1) / 64 : (h->H + 63) / 64;
     const int rpw = (h->nd + 3) / 4;
+    const int rows2 = 2 * ((h->nd + 1) / 2);
+    int ts = h->H; // row stride = 4 mod 16 float2: the (row pair, k1) lanes of the row pass spread over the banks
+    while (ts % 16 != 4)
+      ts++;
     // small variant (see wide2_kernel_small): measured at 224^2 against the tiled kernel / the 31-row template / the
     // two-wave instantiation: +-20 px 24.3 vs 20.7 M/s, +-24 px 22.7 vs 17.7, +-15 px 32.8 vs 31.7, +-12 px 33.5 vs 34.6
     // -> used from 32 rows on
-    const bool small = nblk == 2 && rpw <= 13 && !nyq && (R == 32 || R == 16 || R == 8) && !getenv("BIOEM_NO_WIDE2_SMALL");
+    // (three blocks per CU must fit: at 256^2 the 13-row variant does not -- +-24 px 11.8 vs 14.9 M/s for the two-wave
+    // instantiation -- the 11-row one does: +-16 px 17.4 -> 23.2, +-20 px 17.4 -> 17.7)
+    const bool small = nblk == 2 && rpw <= 13 && (R == 32 || ((R == 16 || R == 8) && !nyq)) &&
+                       wide2_lds_bytes(N, R == 32 ? 16 : R, rows2, ts) <= 160 * 1024 / 3 && !getenv("BIOEM_NO_WIDE2_SMALL");
     // the same for one column block (measured: 128^2 +-40 px 21.1 -> 23.3, +-30 px 27.8 -> 38.6, 120^2 +-25 px 29.2 -> 38.6)
     const bool small1 = nblk == 1 && rpw <= 21 && (R == 32 || ((R == 16 || R == 8) && !nyq)) &&
                         !getenv("BIOEM_NO_WIDE2_SMALL");
     if ((small || small1) && R == 32)
       R = 16;
-    const int rows2 = 2 * ((h->nd + 1) / 2);
-    int ts = h->H; // row stride = 4 mod 16 float2: the (row pair, k1) lanes of the row pass spread over the banks
-    while (ts % 16 != 4)
-      ts++;
     const int N1 = N / R;
     // measured against the tiled k_compare_wide (224^2): +-20 px (two 21-row tiles per axis) 15.9 vs 20.7 M/s, +-30 px
     // (three tiles) 14.8 vs 9.6, +-40 px 12.5 vs 7.2; with a T block beyond 80 KiB only one block fits a CU (256^2
@@ -950,7 +955,7 @@ static int create_impl(bioem_hip_handle *out, int device, const bioem_hip_param_
       if (nyq)
         h->winD = h->nyqWD; // sizes the Nyquist pre-kernel's tables
       HIP_CHECK(h, hipFuncSetAttribute(reinterpret_cast<const void *>(small1            ? wide2_kernel_small1(R, nyq)
-                                                                     : h->w2NRW <= 13 ? wide2_kernel_small(R, h->w2NRW)
+                                                                     : h->w2NRW <= 13 ? wide2_kernel_small(R, h->w2NRW, nyq)
                                                                                       : wide2_kernel(R, nblk, nyq)),
                                        hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int) wide2_lds_bytes(N, R, rows2, ts)));

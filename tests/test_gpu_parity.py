@@ -811,7 +811,10 @@ def test_image_sizes_against_oracle(N, maxD, grid, fast, algo):
                                          (34, 16, 1), (128, 62, 2),
                                          # three waves per SIMD variant (<= 11 rows per wave, two column blocks, R 16 / 8)
                                          (240, 18, 1), (200, 20, 1), (160, 17, 1), (224, 12, 1), (224, 21, 1),
-                                         (208, 44, 2), (224, 24, 1), (200, 25, 1), (160, 26, 1)])
+                                         (208, 44, 2), (224, 24, 1), (200, 25, 1), (160, 26, 1),
+                                         # ... with the Nyquist split (256^2, 128^2) and one column block
+                                         (256, 16, 1), (256, 20, 1), (128, 20, 1), (128, 30, 1), (120, 25, 1),
+                                         (96, 20, 1)])
 @pytest.mark.parametrize("algo", [1, 2])
 def test_wide2_kernel_against_oracle(N, maxD, grid, algo, monkeypatch):
     from bioem_amd.synthetic import Workload
