@@ -896,7 +896,13 @@ static int create_impl(bioem_hip_handle *out, int device, const bioem_hip_param_
   // wide windows, first choice: k_compare_wide2 (one launch per batch, shared column transforms, row FFT).  Needs an
   // even image size with at most two 64-column blocks, at most 32 (one block) / 21 (two blocks) window rows per wave,
   // and its T block [rows][H] in LDS
-  if (N % 2 == 0 && N >= 8 && (mD > 15 || h->nd > 31 || (getenv("BIOEM_FORCE_WIDE2") && h->nd >= 21)) &&
+  // ... and for the 23..31-row windows where the 27/31-row templates of k_compare_fast are weak: the sizes that keep
+  // 32-point FFTs there (Nyquist split: 128^2 +-15 px 47.7 -> 54.8 M/s, 256^2 20.8 -> 24.0) and images whose second
+  // column block is mostly empty (160^2 +-15 px 36.1 -> 43.9, 192^2 33.8 -> 38.1); at 200^2 / 224^2 / 240^2 the two tie
+  // (31.5 / 33.6 / 29.8 vs 29.8 / 32.6 / 29.7) and at 96^2 the template wins (73.1 vs 67.8): those keep it
+  const bool nyqSize0 = BIOEM_NYQUIST_SPLIT && N % 2 == 0 && (N / 2) % 64 == 0;
+  const bool midWindow = h->nd > 21 && h->nd <= 31 && (nyqSize0 || (h->H > 64 && h->H <= 100));
+  if (N % 2 == 0 && N >= 8 && (mD > 15 || h->nd > 31 || midWindow || (getenv("BIOEM_FORCE_WIDE2") && h->nd >= 21)) &&
       h->nd == 2 * mD + 1 && !getenv("BIOEM_NO_WIDE2"))
   {
     int R = (N % 32 == 0) ? 32 : (N % 16 == 0) ? 16 : (N % 8 == 0) ? 8 : (N % 4 == 0) ? 4 : 2;
@@ -933,7 +939,7 @@ static int create_impl(bioem_hip_handle *out, int device, const bioem_hip_param_
     // measured against the tiled k_compare_wide (224^2): +-20 px (two 21-row tiles per axis) 15.9 vs 20.7 M/s, +-30 px
     // (three tiles) 14.8 vs 9.6, +-40 px 12.5 vs 7.2; with a T block beyond 80 KiB only one block fits a CU (256^2
     // +-40 px: 5.5 vs 6.2) -> this kernel from three tiles per axis on, while two blocks per CU fit
-    const bool pays = ((h->nd > 42 || ((small || small1) && h->nd > 31)) &&
+    const bool pays = ((h->nd > 42 || ((small || small1) && (h->nd > 31 || midWindow))) &&
                        wide2_lds_bytes(N, R, rows2, ts) <= 80 * 1024) ||
                       getenv("BIOEM_FORCE_WIDE2");
     if (pays && nblk <= 2 && rpw <= (nblk == 1 ? 32 : 21) && N1 <= 32 && h->nd <= 128 && (!nyq || mD <= 42) &&
