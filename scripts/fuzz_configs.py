@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """One-off fuzz (GPU box): seeded random configurations of the comparison kernels against the CPU oracle.
-usage: python scripts/fuzz_configs.py"""
+usage: python scripts/fuzz_configs.py [first_seed last_seed]   (100 configurations per seed; default seeds 1..6)"""
 import sys, os
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for _p in (ROOT, os.path.join(ROOT, 'tests'), os.path.join(ROOT, 'oracle')):
@@ -9,7 +9,8 @@ import numpy as np
 import test_gpu_parity as T
 from bioem_amd.synthetic import Workload
 bad = 0
-for seed in (1, 2, 3, 4, 5, 6):
+lo, hi = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (1, 6)
+for seed in range(lo, hi + 1):
     for cfg in T._random_configs(100, seed):
         N, maxD, grid, algo, nEnv, nP, nO = cfg
         try:
