@@ -369,40 +369,106 @@ __global__ __launch_bounds__(256, (NRW * NBLK <= 26 && R <= 16) ? 3 : 2) void k_
     const int res = ((dy % R) + R) % R;
     const int step = dy < 0 ? dy + N : dy;
     const int iyr = dinv[dyi];         // visiting rank
-    for (int pj = act ? g : npw; pj < npw; pj += G)
+    // two row pairs per step: their recombination sums and the four log posteriors are independent chains that
+    // overlap each other's LDS and double-precision latencies (two waves per SIMD hide little of them)
+    // (measured: +4 % at +-40 px for the two-wave instantiations, -2..-4 % for the three-wave ones, which keep one pair)
+    constexpr int PPS = (NRW * NBLK <= 26 && R <= 16) ? 1 : 2;
+    // the lane's N1 - 1 recombination twiddles depend on dy only: for N1 <= 8 they are fetched once per chunk and
+    // stay in registers over all row pairs (entries beyond N1 are zero and multiply a clamped, finite y)
+#ifndef BIOEM_W2_K1H
+#define BIOEM_W2_K1H 8
+#endif
+    constexpr int K1H = BIOEM_W2_K1H;
+    const bool hoist = N1 <= K1H;
+    float2 wk[K1H];
+    if (hoist)
     {
-      const int pair = pj0 + pj;
-      const float2 *yp = Tl + (size_t) (2 * pair) * TS + res * N1;
-      float2 y = yp[0];
-      float sr = y.x, si = y.y; // k1 = 0: twiddle 1
       int idx = 0;
-#pragma unroll 4
-      for (int k1 = 1; k1 < N1; k1++)
+#pragma unroll
+      for (int k1 = 1; k1 < K1H; k1++)
       {
         idx += step;
         if (idx >= N)
           idx -= N;
-        const float2 w = twl[idx];
-        y = yp[k1];
-        sr = fmaf(y.x, w.x, sr);
-        sr = fmaf(-y.y, w.y, sr);
-        si = fmaf(y.x, w.y, si);
-        si = fmaf(y.y, w.x, si);
+        wk[k1] = k1 < N1 ? twl[idx] : make_float2(0.f, 0.f);
+      }
+    }
+    for (int pj = act ? g : npw; pj < npw; pj += PPS * G)
+    {
+      const float2 *yp[PPS];
+      float sr[PPS], si[PPS];
+      int pairs[PPS];
+      bool pv[PPS];
+#pragma unroll
+      for (int u = 0; u < PPS; u++)
+      {
+        pv[u] = pj + u * G < npw;
+        pairs[u] = pj0 + (pv[u] ? pj + u * G : pj);
+        yp[u] = Tl + (size_t) (2 * pairs[u]) * TS + res * N1;
+        const float2 y = yp[u][0];
+        sr[u] = y.x; // k1 = 0: twiddle 1
+        si[u] = y.y;
+      }
+      if (hoist)
+      {
+        float2 yv[PPS][K1H];
+#pragma unroll
+        for (int k1 = 1; k1 < K1H; k1++)
+#pragma unroll
+          for (int u = 0; u < PPS; u++)
+            yv[u][k1] = yp[u][min(k1, N1 - 1)];
+#pragma unroll
+        for (int k1 = 1; k1 < K1H; k1++)
+#pragma unroll
+          for (int u = 0; u < PPS; u++)
+          {
+            sr[u] = fmaf(yv[u][k1].x, wk[k1].x, sr[u]);
+            sr[u] = fmaf(-yv[u][k1].y, wk[k1].y, sr[u]);
+            si[u] = fmaf(yv[u][k1].x, wk[k1].y, si[u]);
+            si[u] = fmaf(yv[u][k1].y, wk[k1].x, si[u]);
+          }
+      }
+      else
+      {
+        int idx = 0;
+#pragma unroll 2
+        for (int k1 = 1; k1 < N1; k1++)
+        {
+          idx += step;
+          if (idx >= N)
+            idx -= N;
+          const float2 w = twl[idx];
+#pragma unroll
+          for (int u = 0; u < PPS; u++)
+          {
+            const float2 y = yp[u][k1];
+            sr[u] = fmaf(y.x, w.x, sr[u]);
+            sr[u] = fmaf(-y.y, w.y, sr[u]);
+            si[u] = fmaf(y.x, w.y, si[u]);
+            si[u] = fmaf(y.y, w.x, si[u]);
+          }
+        }
+      }
+      float ccv[2 * PPS];
+      double lpv[2 * PPS];
+#pragma unroll
+      for (int v = 0; v < 2 * PPS; v++)
+      {
+        const float cc = ((v & 1) ? si[v >> 1] : sr[v >> 1]) / nn;
+        ccv[v] = cc;
+        // bioem_algorithm.h:32-36, float expression in the reference's order
+        const float firstele = Np * (sumsqref * q.sumsquareC - cc * cc) + 2 * sumref * q.sumC * cc -
+                               sumsqref * q.sumC * q.sumC - sumref * sumref * q.sumsquareC;
+        double lp = A * log_of_float(firstele, ltab) + t2;
+        lp -= prior;
+        lpv[v] = lp;
       }
 #pragma unroll
-      for (int e = 0; e < 2; e++)
+      for (int v = 0; v < 2 * PPS; v++)
       {
-        const int m = 2 * pair + e;
-        if (m < nd)
-        {
-          const float cc = (e ? si : sr) / nn;
-          // bioem_algorithm.h:32-36, float expression in the reference's order
-          const float firstele = Np * (sumsqref * q.sumsquareC - cc * cc) + 2 * sumref * q.sumC * cc -
-                                 sumsqref * q.sumC * q.sumC - sumref * sumref * q.sumsquareC;
-          double lp = A * log_of_float(firstele, ltab) + t2;
-          lp -= prior;
-          lsef_push(L, lp, dinv[m] * nd + iyr, cc, a.algo);
-        }
+        const int m = 2 * pairs[v >> 1] + (v & 1);
+        if (pv[v >> 1] && m < nd)
+          lsef_push(L, lpv[v], dinv[m] * nd + iyr, ccv[v], a.algo);
       }
     }
   }
