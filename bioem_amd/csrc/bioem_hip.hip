@@ -398,9 +398,9 @@ fast_kernel_t wide2_kernel(int R, int nblk, bool nyq)
   }
 }
 size_t wide2_lds_bytes(int N, int R, int rows2, int ts)
-{ // tables (twiddles, visiting ranks, log table, wave results) + max(four FFT-output slots, T block)
+{ // tables (twiddles, visiting ranks, log table, wave results, posterior constants) + max(four FFT-output slots, T block)
   const size_t slots = (size_t) 4 * R * 64 * 8, tblock = (size_t) rows2 * ts * 8;
-  return (size_t) ((N + 2) & ~1) * 8 + 512 + 1024 + 128 + std::max(slots, tblock);
+  return (size_t) ((N + 2) & ~1) * 8 + 512 + 1024 + 192 + std::max(slots, tblock);
 }
 
 template <int WD>
