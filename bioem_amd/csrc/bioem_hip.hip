@@ -935,6 +935,12 @@ static int create_impl(bioem_hip_handle *out, int device, const bioem_hip_param_
                         !getenv("BIOEM_NO_WIDE2_SMALL");
     if ((small || small1) && R == 32)
       R = 16;
+    // two column blocks of up to 21 rows per wave: with 16-point FFTs the kernel needs 146 registers (three waves per
+    // SIMD) and half the slot space -- worth it exactly where three blocks per CU then fit (224^2 +-26 px: 17.6 -> 18.7
+    // M/s; one row more and only two fit: 14.3)
+    if (R == 32 && nblk == 2 && !small && wide2_lds_bytes(N, 16, rows2, ts) <= 160 * 1024 / 3 &&
+        !getenv("BIOEM_NO_WIDE2_SMALL"))
+      R = 16;
     const int N1 = N / R;
     // measured against the tiled k_compare_wide (224^2): +-20 px (two 21-row tiles per axis) 15.9 vs 20.7 M/s, +-30 px
     // (three tiles) 14.8 vs 9.6, +-40 px 12.5 vs 7.2; with a T block beyond 80 KiB only one block fits a CU (256^2

@@ -56,7 +56,7 @@ __device__ __forceinline__ const_float2_ptr as_constant(const float2 *p)
 }
 
 template <int R, int NRW, int NBLK, bool NYQ>
-__global__ __launch_bounds__(256, (NRW * NBLK <= 26 && R <= 16) ? 3 : 2) void k_compare_wide2(const CompareArgs a)
+__global__ __launch_bounds__(256, (NRW * NBLK <= 42 && R <= 16) ? 3 : 2) void k_compare_wide2(const CompareArgs a)
 {
   constexpr int R2 = R / 2;
   // depth of the operand ring (divides R2): the first RD row pairs of a wave's next step are issued before the
@@ -153,14 +153,18 @@ __global__ __launch_bounds__(256, (NRW * NBLK <= 26 && R <= 16) ? 3 : 2) void k_
       Ti[b][d] = 0.f;
     }
   __syncthreads();
-  // LDS position (float2 units, lane included) of window row d's residue row inside a slot
-  int yoff[NRW];
-#pragma unroll
-  for (int d = 0; d < NRW; d++)
+  // LDS position of window row d's residue row inside a slot: lane addresses held in registers over the column pass,
+  // except in the 8-point instantiations, which form the wave-uniform part on the scalar side where it is used
+  // (measured: registers +1 % for R >= 16, scalar +8 % for R = 8 at 120^2 +-25 px)
+  constexpr bool YOFF_REGS = R > 8;
+  const int dx0 = (r0 - mD) * gs;
+  const int res0 = ((dx0 % R) + R) % R; // residue of the wave's first row; row d: (res0 + d gs) mod R
+  int yoff[YOFF_REGS ? NRW : 1];
+  if (YOFF_REGS)
   {
-    const int m = min(r0 + d, nd - 1);
-    const int dx = (m - mD) * gs;
-    yoff[d] = (((dx % R) + R) % R) * 64 + lane;
+#pragma unroll
+    for (int d = 0; d < NRW; d++)
+      yoff[YOFF_REGS ? d : 0] = ((res0 + d * gs) % R) * 64 + lane;
   }
   // particle row pairs of this wave's NEXT step may be requested as soon as the current step's outputs are parked
   // (BIOEM_W2_FNEXT; measured: -1.6 %, and the kernel without ANY operand traffic -- zero-record descriptors -- is only
@@ -168,11 +172,12 @@ __global__ __launch_bounds__(256, (NRW * NBLK <= 26 && R <= 16) ? 3 : 2) void k_
 #ifndef BIOEM_W2_FNEXT
 #define BIOEM_W2_FNEXT 0
 #endif
-  u32x4 fx[R2];
+  constexpr int RF = R2;
+  u32x4 fx[RF];
   bool fready = false;
   auto request_f = [&](int k1n, unsigned laneoffn) {
 #pragma unroll
-    for (int t = 0; t < R2; t++)
+    for (int t = 0; t < RF; t++)
       fx[t] = __builtin_amdgcn_raw_buffer_load_b128(rsrcF, laneoffn, (unsigned) (k1n * R2 + t) * rowbytes, 0);
   };
 #pragma unroll
@@ -206,7 +211,7 @@ __global__ __launch_bounds__(256, (NRW * NBLK <= 26 && R <= 16) ? 3 : 2) void k_
 #pragma unroll
           for (int k2p = 0; k2p < R2; k2p++)
           {
-            const float4 f = as_float4(fx[k2p]);
+            const float4 f = as_float4(fx[k2p % RF]);
             const float4 c = as_float4(rc[k2p % RC]);
             // X = conv * conj(ref)   (bioem.cpp:1452-1455)
             xr[FFT_IN(2 * k2p)] = fmaf(c.x, f.x, c.y * f.y);
@@ -267,7 +272,7 @@ __global__ __launch_bounds__(256, (NRW * NBLK <= 26 && R <= 16) ? 3 : 2) void k_
               {
                 const int d = d0 + e < NRW ? d0 + e : NRW - 1;
                 w[e] = make_float2(twk[d].x, twk[d].y);
-                y[e] = ys[yoff[d]];
+                y[e] = YOFF_REGS ? ys[yoff[YOFF_REGS ? d : 0]] : ys[((res0 + d * gs) % R) * 64 + lane];
               }
 #pragma unroll
               for (int e = 0; e < FC; e++)
