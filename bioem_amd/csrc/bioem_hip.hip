@@ -145,6 +145,7 @@ struct bioem_hip_ctx
   float *dScratch = nullptr;   // [maxOC][M] ordered |X|^2 terms for sumsquareC
   float2 *dConv = nullptr;     // [maxOC][M] comparison layout
   bioem_hip_param5 *dParams = nullptr;
+  double2 *dPostC = nullptr;    // [maxOC] {t2, prior} of the log posterior per (orientation, CTF) row (k_posterior_consts)
   Partial *dPartials = nullptr; // [nMaps][maxOC]
   unsigned char *dProb = nullptr;
   size_t probBytes = 0;    // bytes start_run / finish_run move (shard handles: the map entries only)
@@ -166,6 +167,7 @@ struct bioem_hip_ctx
   float *dScratch2 = nullptr;
   float2 *dConv2 = nullptr;
   bioem_hip_param5 *dParams2 = nullptr;
+  double2 *dPostC2 = nullptr;
   hipEvent_t prepDone[2] = {nullptr, nullptr};
   hipEvent_t cmpDone[2] = {nullptr, nullptr};
   bool cmpPending[2] = {false, false};
@@ -270,15 +272,16 @@ struct BatchBuf
   float *scratch;
   float2 *conv;
   bioem_hip_param5 *params;
+  double2 *postc;
 };
 
 BatchBuf batch_buf(bioem_hip_ctx *h, int which)
 {
   BatchBuf b;
   if (which == 0)
-    b = {h->dProjReal, h->dTempDen, h->dRowSpec, h->dSpecRef, h->dScratch, h->dConv, h->dParams};
+    b = {h->dProjReal, h->dTempDen, h->dRowSpec, h->dSpecRef, h->dScratch, h->dConv, h->dParams, h->dPostC};
   else
-    b = {h->dProjReal2, h->dTempDen2, h->dRowSpec2, h->dSpecRef2, h->dScratch2, h->dConv2, h->dParams2};
+    b = {h->dProjReal2, h->dTempDen2, h->dRowSpec2, h->dSpecRef2, h->dScratch2, h->dConv2, h->dParams2, h->dPostC2};
   return b;
 }
 
@@ -442,6 +445,7 @@ int launch_compare_fold(bioem_hip_ctx *h, const BatchBuf &bb, int nOC, int orien
   a.ref = h->dRef;
   a.conv = bb.conv;
   a.params = bb.params;
+  a.postc = bb.postc;
   a.sumRef = h->dSumRef;
   a.sumsqRef = h->dSumsqRef;
   a.tw = h->dTw;
@@ -476,6 +480,8 @@ int launch_compare_fold(bioem_hip_ctx *h, const BatchBuf &bb, int nOC, int orien
     h->err = "hipEventCreate failed";
     return 1;
   }
+  // {t2, prior} of every row of the launch, once per row instead of once per comparison and lane
+  hipLaunchKernelGGL(k_posterior_consts, dim3((nOC + 63) / 64), dim3(64), 0, h->stream, bb.params, h->pd, bb.postc, nOC);
   HIP_CHECK(h, hipEventRecord(e0, h->stream));
   if (h->wide2)
   {
@@ -1131,6 +1137,7 @@ static int create_impl(bioem_hip_handle *out, int device, const bioem_hip_param_
   HIP_CHECK(h, hipMalloc(&h->dScratch, sizeof(float) * (size_t) h->maxOC * M));
   HIP_CHECK(h, hipMalloc(&h->dConv, sizeof(float2) * (size_t) h->maxOC * M));
   HIP_CHECK(h, hipMalloc(&h->dParams, sizeof(bioem_hip_param5) * h->maxOC));
+  HIP_CHECK(h, hipMalloc(&h->dPostC, sizeof(double2) * h->maxOC));
   HIP_CHECK(h, hipMalloc(&h->dPartials, sizeof(Partial) * (size_t) nMaps * h->maxOC));
   if (h->nyq)
     HIP_CHECK(h, hipMalloc(&h->dTnyq, sizeof(float) * (size_t) nMaps * h->maxOC * (2 * h->winD + 1)));
@@ -1173,6 +1180,7 @@ static int create_impl(bioem_hip_handle *out, int device, const bioem_hip_param_
   HIP_CHECK(h, hipMalloc(&h->dScratch2, sizeof(float) * (size_t) h->maxOC * M));
   HIP_CHECK(h, hipMalloc(&h->dConv2, sizeof(float2) * (size_t) h->maxOC * M));
   HIP_CHECK(h, hipMalloc(&h->dParams2, sizeof(bioem_hip_param5) * h->maxOC));
+  HIP_CHECK(h, hipMalloc(&h->dPostC2, sizeof(double2) * h->maxOC));
   for (int i = 0; i < 2; i++)
   {
     HIP_CHECK(h, hipEventCreateWithFlags(&h->prepDone[i], hipEventDisableTiming));
@@ -1281,7 +1289,7 @@ int bioem_hip_destroy(bioem_hip_handle h)
                   h->dScratch, h->dConv,    h->dParams,   h->dPartials, h->dProb,
                   h->dProjReal2, h->dTempDen2, h->dRowSpec2, h->dSpecRef2, h->dScratch2, h->dConv2, h->dParams2,
                   h->dTnyq, h->dTwNyq, h->dPartTiles, h->dConvShift, h->dDispLocal, h->dRankOfRow, h->dTileCenter, h->dTileValid,
-                  h->dCand, h->dSend, h->dRecv, h->dMerged, h->dTwk2};
+                  h->dCand, h->dSend, h->dRecv, h->dMerged, h->dTwk2, h->dPostC, h->dPostC2};
   for (void *p : ptrs)
     if (p)
       hipFree(p);

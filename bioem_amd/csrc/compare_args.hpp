@@ -11,6 +11,7 @@ struct CompareArgs
   const float2 *ref;  // [nMaps][M] comparison layout
   const float2 *conv; // [nOC][M]
   const bioem_hip_param5 *params;
+  const double2 *postc; // [nOC] {t2, prior} of logpro_consts, evaluated once per row by k_posterior_consts
   const float *sumRef, *sumsqRef;
   const float2 *tw; // N+1
   const int *disp;  // nd

@@ -422,8 +422,8 @@ __global__ __launch_bounds__(256, fast_waves_per_simd(WD, R)) void k_compare_fas
 
   const bioem_hip_param5 q = a.params[oc];
   const float sumref = a.sumRef[p], sumsqref = a.sumsqRef[p];
-  double t2, prior;
-  logpro_consts(a.pd, q, t2, prior);
+  const double2 pc = a.postc[oc];
+  const double t2 = pc.x, prior = pc.y;
   const float Np = a.pd.Ntotpi;
   const double A = (double) (3 - Np) * 0.5;
   const float nn = (float) (N * N);

@@ -94,8 +94,8 @@ __global__ __launch_bounds__(256) void k_compare_generic(const CompareArgs a)
   __syncthreads();
 
   const bioem_hip_param5 q = a.params[oc];
-  double t2, prior;
-  logpro_consts(a.pd, q, t2, prior);
+  const double2 pc = a.postc[oc];
+  const double t2 = pc.x, prior = pc.y;
   const float sumref = a.sumRef[p], sumsqref = a.sumsqRef[p];
   const float nn = (float) (N * N);
   Lse L;

@@ -175,8 +175,8 @@ __global__ __launch_bounds__(256, (WD <= 10 ? 3 : 2)) void k_compare_rows(const 
 
   const bioem_hip_param5 q = a.params[oc];
   const float sumref = a.sumRef[p], sumsqref = a.sumsqRef[p];
-  double t2, prior;
-  logpro_consts(a.pd, q, t2, prior);
+  const double2 pc = a.postc[oc];
+  const double t2 = pc.x, prior = pc.y;
   const float Np = a.pd.Ntotpi;
   const double A = (double) (3 - Np) * 0.5;
   const float nn = (float) (N * N);
@@ -391,8 +391,8 @@ __global__ __launch_bounds__(256, (WD <= 10 ? 3 : 2)) void k_compare_oddfft(cons
 
   const bioem_hip_param5 q = a.params[oc];
   const float sumref = a.sumRef[p], sumsqref = a.sumsqRef[p];
-  double t2, prior;
-  logpro_consts(a.pd, q, t2, prior);
+  const double2 pc = a.postc[oc];
+  const double t2 = pc.x, prior = pc.y;
   const float Np = a.pd.Ntotpi;
   const double A = (double) (3 - Np) * 0.5;
   const float nn = (float) (N * N);

@@ -106,14 +106,14 @@ __global__ __launch_bounds__(256, (NRW * NBLK <= 42 && R <= 16) ? 3 : 2) void k_
     oc = rem / pc;
     p = c * a.pchunk + (rem - oc * pc);
   }
-  // constants of the comparison's posterior: fetched and evaluated by wave 0 while the tables load (read where the
-  // posterior starts, their two L2 round trips and the double-precision setup were exposed in all four waves)
+  // constants of the comparison's posterior: fetched by wave 0 while the tables load (read where the posterior
+  // starts, their L2 round trips were exposed in all four waves)
   if (wave == 0)
   {
     const bioem_hip_param5 q = a.params[oc];
     const float sumref = a.sumRef[p], sumsqref = a.sumsqRef[p];
-    double t2, prior;
-    logpro_consts(a.pd, q, t2, prior);
+    const double2 pc = a.postc[oc];
+    const double t2 = pc.x, prior = pc.y;
     if (lane == 0)
     {
       cst->t2 = t2;

@@ -37,6 +37,19 @@ __device__ __forceinline__ void logpro_consts(const PD &pd, const bioem_hip_para
   }
 }
 
+// the two constants of every (orientation, CTF) row of a launch, for the comparison kernels to read
+__global__ __launch_bounds__(64) void k_posterior_consts(const bioem_hip_param5 *__restrict__ params, const PD pd,
+                                                         double2 *__restrict__ out, int n)
+{
+  const int i = blockIdx.x * 64 + threadIdx.x;
+  if (i < n)
+  {
+    double t2, prior;
+    logpro_consts(pd, params[i], t2, prior);
+    out[i] = make_double2(t2, prior);
+  }
+}
+
 __device__ __forceinline__ double logpro_eval(const PD &pd, const bioem_hip_param5 &q, float cc, float sumref,
                                               float sumsqref, double t2, double prior)
 {
