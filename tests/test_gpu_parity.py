@@ -945,6 +945,50 @@ def test_config3_shape_ten_ctfs_two_shards():
     E.close()
 
 
+def test_config4_shape_against_direct_real_space_correlation():
+    """BASELINE config 4 (FFT-free sliding-window algorithm, 128^2, 4 608 orientations) has no implementation in the
+    reference; what it would compute is the SAME posterior from the real-space cross-correlation
+    cc(dx, dy) = sum_xy conv(x + dx, y + dy) * particle(x, y) (circular), the identity behind the c2r transform of
+    bioem.cpp:1452-1458.  The product path at the config-4 shape is checked against that definition evaluated directly
+    in float64 (numpy) with the oracle's calc_logpro, plus the size-independent properties."""
+    import ctypes as C
+    import bioem_amd.engine as eng
+    from bioem_amd.synthetic import Workload
+    W = Workload(N=128, nP=64, nOrient=4608, nEnv=1, maxD=10)
+    N, mD = W.N, 10
+    raw, full = run_workload(W, 0, W.nOrient)
+    raw2, _ = run_workload(W, 0, W.nOrient)
+    assert raw.tobytes() == raw2.tobytes()
+    truth = (7919 * np.arange(W.nP)) % W.nOrient
+    assert np.mean(full["orient"] == truth) > 0.9
+    _, sumRef, sumsqRef = W.engine.debug_particles()
+    pd = orc.ParamDevice()
+    for f, _ in orc.ParamDevice._fields_:
+        setattr(pd, f, getattr(W.pd, f))
+    amp, pha, env = (np.float32(v) for v in W.ctfParam[0])
+    L = orc.lib()
+    for p, o in [(0, int(truth[0])), (17, int(truth[17])), (63, 5)]:
+        spec, sumC, sumsqC = W.engine.debug_convolution(o, 0)
+        conv = np.fft.irfft2(spec[..., 0].astype(np.float64) + 1j * spec[..., 1].astype(np.float64), s=(N, N))
+        part = W.maps[p].astype(np.float64)
+        lp = np.empty((2 * mD + 1, 2 * mD + 1))
+        for dx in range(-mD, mD + 1):
+            for dy in range(-mD, mD + 1):
+                cc = np.float32(np.sum(np.roll(conv, (-dx, -dy), axis=(0, 1)) * part))
+                lp[dx + mD, dy + mD] = L.orc_calc_logpro(C.byref(pd), amp, pha, env, sumC, sumsqC, cc, sumRef[p],
+                                                         sumsqRef[p])
+        m = lp.max()
+        want = m + np.log(np.exp(lp - m).sum())
+        bx, by = np.unravel_index(np.argmax(lp), lp.shape)
+        r1, got = run_workload(W, o, o + 1)
+        g = got[p]
+        have = np.log(g["Total"]) + g["Constoadd"]
+        assert abs(have - want) <= REL_TOL * abs(want) and abs(have - want) <= ABS_TOL
+        # the reference reports the NEGATIVE displacement of the best match (bioem_algorithm.h:95-96)
+        assert (g["orient"], g["conv"], g["cent_x"], g["cent_y"]) == (o, 0, -(bx - mD), -(by - mD))
+    W.engine.close()
+
+
 def test_cli_model_formats_pdb_and_mrc(tmp_path):
     """--ReadPDB and --ReadModelMRC through the CLI against the oracle fed with the same points."""
     from bioem_amd import hostlib
