@@ -1030,9 +1030,11 @@ static int create_impl(bioem_hip_handle *out, int device, const bioem_hip_param_
     if (R < 8 && h->gs == 1 && !getenv("BIOEM_POW2_FFT"))
     { // power-of-two part 2 or 4: the largest 2/3/5-smooth even divisor <= 30 (mixed-radix register FFT) wins
       // (measured: 250^2 20 -> 40 M/s, 180^2 47 -> 53, 100^2 129 -> 143; with a part of 8 it does not: 200^2, 120^2)
+      // 27/31-row windows: lengths up to 16 keep three waves per SIMD (fast_half_t), as for the powers of two
       static const int mixed[] = {30, 20, 18, 12, 10, 6};
+      const bool small16 = h->winD > 10 && fast_half_t(15, 16) && !getenv("BIOEM_WIDE_R32");
       for (int r : mixed)
-        if (N % r == 0 && r > R)
+        if (N % r == 0 && r > R && !(small16 && r > 16))
         {
           R = r;
           break;

@@ -775,6 +775,10 @@ def test_config5_shape_two_shards_device_top_k(tmp_path):
                                               # 31-row window: R = 16 + half-width T exchange (3 waves per SIMD); with
                                               # the Nyquist split (128) it stays at R = 32
                                               (224, 13, 1, 1), (128, 15, 1, 1), (160, 12, 1, 1), (200, 15, 1, 1),
+                                              # ... and the mixed-radix sizes with a length <= 16 (180 -> 12, 150 -> 10,
+                                              # 100 -> 10, 300 -> 12, 90 -> 10, 84 -> 12, 42 -> 6) instead of 30 / 20 / 18
+                                              (180, 15, 1, 1), (150, 12, 1, 1), (100, 15, 1, 1), (300, 13, 1, 1),
+                                              (90, 11, 1, 1), (84, 14, 1, 1), (42, 15, 1, 1), (180, 30, 2, 1),
                                               # wide windows (the reference's tutorial suggests DISPLACE_CENTER 40 1):
                                               # tiles of the 21- / 31-row window on phase-shifted conv spectra
                                               (64, 20, 1, 1), (128, 40, 1, 1), (224, 20, 1, 1), (100, 40, 2, 1),
