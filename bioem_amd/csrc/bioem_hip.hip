@@ -373,15 +373,30 @@ fast_kernel_t wide2_kernel_small1(int R, bool nyq)
 {
   if (nyq)
     return k_compare_wide2<16, 21, 1, true>;
-  return R == 8 ? k_compare_wide2<8, 21, 1, false> : k_compare_wide2<16, 21, 1, false>;
+  switch (R)
+  {
+  case 8: return k_compare_wide2<8, 21, 1, false>;
+  case 12: return k_compare_wide2<12, 21, 1, false>;
+  case 10: return k_compare_wide2<10, 21, 1, false>;
+  default: return k_compare_wide2<16, 21, 1, false>;
+  }
+}
+template <int NRW>
+fast_kernel_t wide2_kernel_small_n(int R, bool nyq)
+{
+  if (nyq) // N/2 a multiple of 64 (256^2): R = 16 by choice
+    return k_compare_wide2<16, NRW, 2, true>;
+  switch (R)
+  {
+  case 8: return k_compare_wide2<8, NRW, 2, false>;
+  case 12: return k_compare_wide2<12, NRW, 2, false>;
+  case 10: return k_compare_wide2<10, NRW, 2, false>;
+  default: return k_compare_wide2<16, NRW, 2, false>;
+  }
 }
 fast_kernel_t wide2_kernel_small(int R, int nrw, bool nyq)
 {
-  if (nyq) // N/2 a multiple of 64 (256^2): R = 16 by choice
-    return nrw == 13 ? k_compare_wide2<16, 13, 2, true> : k_compare_wide2<16, 11, 2, true>;
-  if (nrw == 13)
-    return R == 8 ? k_compare_wide2<8, 13, 2, false> : k_compare_wide2<16, 13, 2, false>;
-  return R == 8 ? k_compare_wide2<8, 11, 2, false> : k_compare_wide2<16, 11, 2, false>;
+  return nrw == 13 ? wide2_kernel_small_n<13>(R, nyq) : wide2_kernel_small_n<11>(R, nyq);
 }
 fast_kernel_t wide2_kernel(int R, int nblk, bool nyq)
 {
@@ -922,9 +937,29 @@ static int create_impl(bioem_hip_handle *out, int device, const bioem_hip_param_
           break;
         }
     }
+    if (const char *fr = getenv("BIOEM_W2_R"))
+    { // experiments: a given register-FFT length where it divides N
+      const int r = atoi(fr);
+      static const int lens[] = {32, 16, 8, 4, 2, 30, 20, 18, 12, 10, 6};
+      for (int l : lens)
+        if (l == r && N % r == 0)
+          R = r;
+    }
     const bool nyq = BIOEM_NYQUIST_SPLIT && (N / 2) % 64 == 0;
     const int nblk = nyq ? (h->H - 1) / 64 : (h->H + 63) / 64;
     const int rpw = (h->nd + 3) / 4;
+    // the longest length with a three-waves-per-SIMD instantiation (16, 12, 10, 8) that divides N
+    int r3 = 0;
+    if (!getenv("BIOEM_W2_R"))
+    {
+      static const int lens3[] = {16, 12, 10, 8};
+      for (int l : lens3)
+        if (!r3 && N % l == 0 && (l == 16 || !nyq))
+          r3 = l;
+    }
+    else if (R == 16 || ((R == 12 || R == 10 || R == 8) && !nyq))
+      r3 = R;
+    const bool mixedLen = R != 32 && R != 16 && R != 8 && R != 4 && R != 2;
     const int rows2 = 2 * ((h->nd + 1) / 2);
     int ts = h->H; // row stride = 4 mod 16 float2: the (row pair, k1) lanes of the row pass spread over the banks
     while (ts % 16 != 4)
@@ -934,24 +969,38 @@ static int create_impl(bioem_hip_handle *out, int device, const bioem_hip_param_
     // -> used from 32 rows on
     // (three blocks per CU must fit: at 256^2 the 13-row variant does not -- +-24 px 11.8 vs 14.9 M/s for the two-wave
     // instantiation -- the 11-row one does: +-16 px 17.4 -> 23.2, +-20 px 17.4 -> 17.7)
-    const bool small = nblk == 2 && rpw <= 13 && (R == 32 || ((R == 16 || R == 8) && !nyq)) &&
-                       wide2_lds_bytes(N, R == 32 ? 16 : R, rows2, ts) <= 160 * 1024 / 3 && !getenv("BIOEM_NO_WIDE2_SMALL");
-    // the same for one column block (measured: 128^2 +-40 px 21.1 -> 23.3, +-30 px 27.8 -> 38.6, 120^2 +-25 px 29.2 -> 38.6)
-    const bool small1 = nblk == 1 && rpw <= 21 && (R == 32 || ((R == 16 || R == 8) && !nyq)) &&
-                        !getenv("BIOEM_NO_WIDE2_SMALL");
-    if ((small || small1) && R == 32)
-      R = 16;
+    // Mixed-radix sizes take it with a 12- or 10-point FFT (`scripts/w2_length_sweep.sh`: 180^2 +-20 px 21.0 on the
+    // tiled kernel -> 29.5, 150^2 25.9 -> 32.4, 200^2 19.9 with 8 points -> 22.3 with 10)
+    const bool small = nblk == 2 && rpw <= 13 && r3 && wide2_lds_bytes(N, r3, rows2, ts) <= 160 * 1024 / 3 &&
+                       !getenv("BIOEM_NO_WIDE2_SMALL");
+    // the same for one column block (measured: 128^2 +-40 px 21.1 -> 23.3, +-30 px 27.8 -> 38.6, 120^2 +-25 px 29.2 -> 38.6;
+    // 90^2 +-30 px 30.2 with 30 points at two waves -> 43.1 with 10, 120^2 +-30 px 34.9 with 8 -> 39.1 with 12)
+    const bool small1 = nblk == 1 && rpw <= 21 && r3 && !getenv("BIOEM_NO_WIDE2_SMALL");
+    if (small || small1)
+      R = r3;
     // two column blocks of up to 21 rows per wave: with 16-point FFTs the kernel needs 146 registers (three waves per
     // SIMD) and half the slot space -- worth it exactly where three blocks per CU then fit (224^2 +-26 px: 17.6 -> 18.7
     // M/s; one row more and only two fit: 14.3)
     if (R == 32 && nblk == 2 && !small && wide2_lds_bytes(N, 16, rows2, ts) <= 160 * 1024 / 3 &&
         !getenv("BIOEM_NO_WIDE2_SMALL"))
       R = 16;
+    // sizes whose power-of-two part is 8 (200, 120, 280): the two-wave instantiations run faster on the longest
+    // mixed length (200^2 +-30 px 11.2 -> 15.3 M/s, +-40 px 9.2 -> 12.7 with 20 points)
+    if (R == 8 && !small && !small1 && !getenv("BIOEM_W2_R") && !getenv("BIOEM_POW2_FFT"))
+    {
+      static const int mixed[] = {30, 20, 18, 12, 10};
+      for (int r : mixed)
+        if (N % r == 0)
+        {
+          R = r;
+          break;
+        }
+    }
     const int N1 = N / R;
     // measured against the tiled k_compare_wide (224^2): +-20 px (two 21-row tiles per axis) 15.9 vs 20.7 M/s, +-30 px
     // (three tiles) 14.8 vs 9.6, +-40 px 12.5 vs 7.2; with a T block beyond 80 KiB only one block fits a CU (256^2
     // +-40 px: 5.5 vs 6.2) -> this kernel from three tiles per axis on, while two blocks per CU fit
-    const bool pays = ((h->nd > 42 || ((small || small1) && (h->nd > 31 || midWindow))) &&
+    const bool pays = ((h->nd > 42 || ((small || small1) && (h->nd > 31 || (midWindow && !mixedLen)))) &&
                        wide2_lds_bytes(N, R, rows2, ts) <= 80 * 1024) ||
                       getenv("BIOEM_FORCE_WIDE2");
     if (pays && nblk <= 2 && rpw <= (nblk == 1 ? 32 : 21) && N1 <= 32 && h->nd <= 128 && (!nyq || mD <= 42) &&
