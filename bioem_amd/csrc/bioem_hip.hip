@@ -109,7 +109,7 @@ struct bioem_hip_ctx
   // k_compare_wide2 (compare_wide2.hpp): wide window in ONE launch per batch -- column transforms shared by the four
   // waves of a comparison, row FFT
   bool wide2 = false;
-  int w2NRW = 0, w2NBLK = 0, w2TS = 0, w2Rows2 = 0, nyqWD = 0;
+  int w2NRW = 0, w2NBLK = 0, w2TS = 0, w2Rows2 = 0, nyqWD = 0, w2Halves = 1;
   float2 *dTwk2 = nullptr; // [N1][nd] recombination twiddles exp(2 pi i dx k1 / N), rows in sorted order
   float2 *dConvShift = nullptr;
   Partial *dPartTiles = nullptr;
@@ -356,14 +356,17 @@ size_t wide_lds_bytes(int N, int H, int wpc, bool nyq)
 
 // k_compare_wide2 instantiations: every register-FFT length; (rows per wave, column blocks) = (32, 1) or (21, 2)
 template <int R>
-fast_kernel_t wide2_kernel_r(int nblk, bool nyq)
+fast_kernel_t wide2_kernel_r(int nblk, bool nyq, int halves)
 {
   if constexpr (R == 32)
   {
     if (nyq)
-      return nblk == 1 ? k_compare_wide2<32, 32, 1, true> : k_compare_wide2<32, 21, 2, true>;
+      return nblk == 1     ? k_compare_wide2<32, 32, 1, true>
+             : halves == 2 ? k_compare_wide2<32, 21, 2, true, 2>
+                           : k_compare_wide2<32, 21, 2, true>;
   }
-  return nblk == 1 ? k_compare_wide2<R, 32, 1, false> : k_compare_wide2<R, 21, 2, false>;
+  return nblk == 1 ? k_compare_wide2<R, 32, 1, false> : halves == 2 ? k_compare_wide2<R, 21, 2, false, 2>
+                                                                    : k_compare_wide2<R, 21, 2, false>;
 }
 // windows of 32..52 rows (at most 11 / 13 per wave) over two column blocks with 16- or 8-point register FFTs: 44 / 52 T
 // accumulators + a short FFT fit three waves per SIMD, the T block (<= 48 KiB) three blocks per CU
@@ -398,21 +401,21 @@ fast_kernel_t wide2_kernel_small(int R, int nrw, bool nyq)
 {
   return nrw == 13 ? wide2_kernel_small_n<13>(R, nyq) : wide2_kernel_small_n<11>(R, nyq);
 }
-fast_kernel_t wide2_kernel(int R, int nblk, bool nyq)
+fast_kernel_t wide2_kernel(int R, int nblk, bool nyq, int halves = 1)
 {
   switch (R)
   {
-  case 32: return wide2_kernel_r<32>(nblk, nyq);
-  case 16: return wide2_kernel_r<16>(nblk, nyq);
-  case 8: return wide2_kernel_r<8>(nblk, nyq);
-  case 4: return wide2_kernel_r<4>(nblk, nyq);
-  case 2: return wide2_kernel_r<2>(nblk, nyq);
-  case 30: return wide2_kernel_r<30>(nblk, nyq);
-  case 20: return wide2_kernel_r<20>(nblk, nyq);
-  case 18: return wide2_kernel_r<18>(nblk, nyq);
-  case 12: return wide2_kernel_r<12>(nblk, nyq);
-  case 10: return wide2_kernel_r<10>(nblk, nyq);
-  default: return wide2_kernel_r<6>(nblk, nyq);
+  case 32: return wide2_kernel_r<32>(nblk, nyq, halves);
+  case 16: return wide2_kernel_r<16>(nblk, nyq, halves);
+  case 8: return wide2_kernel_r<8>(nblk, nyq, halves);
+  case 4: return wide2_kernel_r<4>(nblk, nyq, halves);
+  case 2: return wide2_kernel_r<2>(nblk, nyq, halves);
+  case 30: return wide2_kernel_r<30>(nblk, nyq, halves);
+  case 20: return wide2_kernel_r<20>(nblk, nyq, halves);
+  case 18: return wide2_kernel_r<18>(nblk, nyq, halves);
+  case 12: return wide2_kernel_r<12>(nblk, nyq, halves);
+  case 10: return wide2_kernel_r<10>(nblk, nyq, halves);
+  default: return wide2_kernel_r<6>(nblk, nyq, halves);
   }
 }
 size_t wide2_lds_bytes(int N, int R, int rows2, int ts)
@@ -517,7 +520,7 @@ int launch_compare_fold(bioem_hip_ctx *h, const BatchBuf &bb, int nOC, int orien
     const size_t lds = wide2_lds_bytes(h->N, 2 * h->fast, h->w2Rows2, h->w2TS);
     hipLaunchKernelGGL(h->w2NBLK == 1 && h->w2NRW == 21 ? wide2_kernel_small1(2 * h->fast, h->nyq)
                        : h->w2NRW <= 13                 ? wide2_kernel_small(2 * h->fast, h->w2NRW, h->nyq)
-                                                        : wide2_kernel(2 * h->fast, h->w2NBLK, h->nyq),
+                                                        : wide2_kernel(2 * h->fast, h->w2NBLK, h->nyq, h->w2Halves),
                        dim3((unsigned) ((size_t) nOC * h->nMaps)), dim3(256), lds, h->stream, aw);
   }
   else if (h->fast || h->rowsK)
@@ -1000,12 +1003,19 @@ static int create_impl(bioem_hip_handle *out, int device, const bioem_hip_param_
     // measured against the tiled k_compare_wide (224^2): +-20 px (two 21-row tiles per axis) 15.9 vs 20.7 M/s, +-30 px
     // (three tiles) 14.8 vs 9.6, +-40 px 12.5 vs 7.2; with a T block beyond 80 KiB only one block fits a CU (256^2
     // +-40 px: 5.5 vs 6.2) -> this kernel from three tiles per axis on, while two blocks per CU fit
+    // a T block that leaves one block per CU goes through LDS in two halves of the window rows where that brings the
+    // second block back (k_compare_wide2<.., HALVES = 2>: 256^2 +-40 px 6.1 on the tiled kernel, 6.7 at one block per CU)
+    const int hrows = (rows2 / 2 + 1) & ~1;
+    const bool halves2 = nblk == 2 && !small && wide2_lds_bytes(N, R, rows2, ts) > 80 * 1024 &&
+                         wide2_lds_bytes(N, R, hrows, ts) <= 80 * 1024 && !getenv("BIOEM_NO_WIDE2_HALVES");
+    const int ldsRows = halves2 ? hrows : rows2;
     const bool pays = ((h->nd > 42 || ((small || small1) && (h->nd > 31 || (midWindow && !mixedLen)))) &&
-                       wide2_lds_bytes(N, R, rows2, ts) <= 80 * 1024) ||
+                       wide2_lds_bytes(N, R, ldsRows, ts) <= 80 * 1024) ||
                       getenv("BIOEM_FORCE_WIDE2");
     if (pays && nblk <= 2 && rpw <= (nblk == 1 ? 32 : 21) && N1 <= 32 && h->nd <= 128 && (!nyq || mD <= 42) &&
-        wide2_lds_bytes(N, R, rows2, ts) <= 160 * 1024)
+        wide2_lds_bytes(N, R, ldsRows, ts) <= 160 * 1024)
     {
+      h->w2Halves = halves2 ? 2 : 1;
       h->wide2 = true;
       h->fast = R / 2;
       h->N1 = N1;
@@ -1017,15 +1027,15 @@ static int create_impl(bioem_hip_handle *out, int device, const bioem_hip_param_
       if (small1)
         h->w2NRW = 21;
       h->w2TS = ts;
-      h->w2Rows2 = rows2;
+      h->w2Rows2 = ldsRows; // rows of the T block in LDS
       h->nyqWD = mD <= 20 ? 20 : mD <= 31 ? 31 : 42;
       if (nyq)
         h->winD = h->nyqWD; // sizes the Nyquist pre-kernel's tables
       HIP_CHECK(h, hipFuncSetAttribute(reinterpret_cast<const void *>(small1            ? wide2_kernel_small1(R, nyq)
                                                                      : h->w2NRW <= 13 ? wide2_kernel_small(R, h->w2NRW, nyq)
-                                                                                      : wide2_kernel(R, nblk, nyq)),
+                                                                                      : wide2_kernel(R, nblk, nyq, h->w2Halves)),
                                        hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int) wide2_lds_bytes(N, R, rows2, ts)));
+                                       (int) wide2_lds_bytes(N, R, ldsRows, ts)));
     }
   }
   if (!h->wide2 && N >= 8 && (mD > 15 || h->nd > 31) && h->nd == 2 * mD + 1 && !getenv("BIOEM_NO_TILES"))
@@ -2051,7 +2061,10 @@ const char *bioem_hip_kernel_signature(bioem_hip_handle h)
   static thread_local char buf[96];
   const char *nq = h->nyq ? "true" : "false";
   if (h->wide2)
-    snprintf(buf, sizeof(buf), "k_compare_wide2<%d, %d, %d, %s>", 2 * h->fast, h->w2NRW, h->w2NBLK, nq);
+    if (h->w2Halves == 2)
+      snprintf(buf, sizeof(buf), "k_compare_wide2<%d, %d, %d, %s, 2>", 2 * h->fast, h->w2NRW, h->w2NBLK, nq);
+    else
+      snprintf(buf, sizeof(buf), "k_compare_wide2<%d, %d, %d, %s>", 2 * h->fast, h->w2NRW, h->w2NBLK, nq);
   else if (h->fast && h->tileT && h->wideWPC)
     snprintf(buf, sizeof(buf), "k_compare_wide<%d, %d, %d, %s>", 2 * h->fast, h->gs, h->wideWPC, nq);
   else if (h->fast)

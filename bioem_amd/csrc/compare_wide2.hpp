@@ -55,7 +55,9 @@ __device__ __forceinline__ const_float2_ptr as_constant(const float2 *p)
   return (const_float2_ptr) (unsigned long long) p;
 }
 
-template <int R, int NRW, int NBLK, bool NYQ>
+// HALVES = 2: the T block goes through LDS in two halves of the window rows (row pass + posterior per half), for the
+// sizes whose whole T block would leave one block per CU (240^2 ... 256^2 at +-35 ... +-42 px)
+template <int R, int NRW, int NBLK, bool NYQ, int HALVES = 1>
 __global__ __launch_bounds__(256, (NRW * NBLK <= 42 && R <= 16) ? 3 : 2) void k_compare_wide2(const CompareArgs a)
 {
   constexpr int R2 = R / 2;
@@ -298,8 +300,25 @@ __global__ __launch_bounds__(256, (NRW * NBLK <= 42 && R <= 16) ? 3 : 2) void k_
     }
   }
   W2_STAMP(0);
+  const bioem_hip_param5 q = cst->q;
+  const float sumref = cst->sumref, sumsqref = cst->sumsqref;
+  const double t2 = cst->t2, prior = cst->prior;
+  const float Np = a.pd.Ntotpi;
+  const double A = (double) (3 - Np) * 0.5;
+  const float nn = (float) (N * N);
+  LseF L;
+  L.m = -INFINITY;
+  L.s = 0.;
+  L.id = 0x7fffffff;
+  L.val = 0.f;
+  const int rows2 = 2 * ((nd + 1) >> 1);
+  const int hrows = HALVES == 1 ? rows2 : ((rows2 / 2 + 1) & ~1);
+#pragma unroll
+  for (int hf = 0; hf < HALVES; hf++)
+  {
   // ---------------- T -> LDS (the slots are dead) ----------------
   float2 *Tl = U;
+  const int h0 = hf * hrows, h1 = min(rows2, h0 + hrows); // window rows of this half (all of them for HALVES = 1)
 #pragma unroll
   for (int blk = 0; blk < NBLK; blk++)
   {
@@ -308,24 +327,24 @@ __global__ __launch_bounds__(256, (NRW * NBLK <= 42 && R <= 16) ? 3 : 2) void k_
     {
 #pragma unroll
       for (int d = 0; d < NRW; d++)
-        if (d < nrows)
-          Tl[(size_t) (r0 + d) * TS + ky] = make_float2(Tr[blk][d], Ti[blk][d]);
+        if (d < nrows && (HALVES == 1 || (r0 + d >= h0 && r0 + d < h1)))
+          Tl[(size_t) (r0 + d - h0) * TS + ky] = make_float2(Tr[blk][d], Ti[blk][d]);
     }
   }
-  if (NYQ && lane < nrows)
+  if (NYQ && lane < nrows && r0 + lane >= h0 && r0 + lane < h1)
   { // Nyquist column from k_nyquist_rows: rows -nyqWD..nyqWD of Re T[.][N/2] (the imaginary part never enters)
     const int NWQ = 2 * a.nyqWD + 1;
     const float *tq = a.tnyq + ((size_t) p * a.ldPart + oc) * NWQ;
-    Tl[(size_t) (r0 + lane) * TS + N / 2] = make_float2(tq[r0 + lane - mD + a.nyqWD], 0.f);
+    Tl[(size_t) (r0 + lane - h0) * TS + N / 2] = make_float2(tq[r0 + lane - mD + a.nyqWD], 0.f);
   }
-  if ((nd & 1) && wave == 3)
+  if ((nd & 1) && wave == 3 && nd >= h0 && nd < h1)
     for (int c = lane; c < H; c += 64) // odd row count: the last pair's second row is empty
-      Tl[(size_t) nd * TS + c] = make_float2(0.f, 0.f);
+      Tl[(size_t) (nd - h0) * TS + c] = make_float2(0.f, 0.f);
   __syncthreads();
 
   W2_STAMP(1);
   // ---------------- row pass: pairs of rows, private to a wave ----------------
-  const int npairs = (nd + 1) >> 1;
+  const int npairs = (h1 - h0) >> 1;
   const int ppw = (npairs + 3) >> 2;
   const int pj0 = wave * ppw;
   const int npw = max(0, min(ppw, npairs - pj0));
@@ -375,17 +394,6 @@ __global__ __launch_bounds__(256, (NRW * NBLK <= 42 && R <= 16) ? 3 : 2) void k_
   W2_STAMP(2);
 
   // ---------------- recombination over k1 + posterior: lanes = dy ----------------
-  const bioem_hip_param5 q = cst->q;
-  const float sumref = cst->sumref, sumsqref = cst->sumsqref;
-  const double t2 = cst->t2, prior = cst->prior;
-  const float Np = a.pd.Ntotpi;
-  const double A = (double) (3 - Np) * 0.5;
-  const float nn = (float) (N * N);
-  LseF L;
-  L.m = -INFINITY;
-  L.s = 0.;
-  L.id = 0x7fffffff;
-  L.val = 0.f;
   for (int c0 = 0; c0 < nd; c0 += 64)
   {
     const int wc = min(64, nd - c0);
@@ -494,11 +502,14 @@ __global__ __launch_bounds__(256, (NRW * NBLK <= 42 && R <= 16) ? 3 : 2) void k_
 #pragma unroll
       for (int v = 0; v < 2 * PPS; v++)
       {
-        const int m = 2 * pairs[v >> 1] + (v & 1);
+        const int m = h0 + 2 * pairs[v >> 1] + (v & 1);
         if (pv[v >> 1] && m < nd)
           lsef_push(L, lpv[v], dinv[m] * nd + iyr, ccv[v], a.algo);
       }
     }
+  }
+    if (hf + 1 < HALVES)
+      __syncthreads(); // every wave is done with this half's rows before the next half overwrites them
   }
   W2_STAMP(3);
   lsef_wave_reduce(L);

@@ -806,6 +806,9 @@ def test_image_sizes_against_oracle(N, maxD, grid, fast, algo):
         W.engine.close()
 
 
+HALVED = {(256, 40), (240, 38), (250, 40), (256, 37), (248, 78)}   # sizes of the list below that take HALVES = 2
+
+
 # k_compare_wide2 (shared column transforms + row FFT) is picked from three 21-row tiles per axis on; forced here for
 # every register-FFT length, one and two column blocks, the Nyquist split, row strides 1..3, odd and even row counts
 # per wave, windows from +-16 to +-41 px
@@ -818,7 +821,10 @@ def test_image_sizes_against_oracle(N, maxD, grid, fast, algo):
                                          (208, 44, 2), (224, 24, 1), (200, 25, 1), (160, 26, 1),
                                          # ... with the Nyquist split (256^2, 128^2) and one column block
                                          (256, 16, 1), (256, 20, 1), (128, 20, 1), (128, 30, 1), (120, 25, 1),
-                                         (96, 20, 1)])
+                                         (96, 20, 1),
+                                         # T block through LDS in two halves (one block per CU otherwise): even / odd halves,
+                                         # Nyquist split, mixed radix, row stride 2
+                                         (256, 40, 1), (240, 38, 1), (250, 40, 1), (256, 37, 1), (248, 78, 2)])
 @pytest.mark.parametrize("algo", [1, 2])
 def test_wide2_kernel_against_oracle(N, maxD, grid, algo, monkeypatch):
     from bioem_amd.synthetic import Workload
@@ -827,6 +833,7 @@ def test_wide2_kernel_against_oracle(N, maxD, grid, algo, monkeypatch):
     W = Workload(N=N, nP=nP, nOrient=nO, nEnv=2, maxD=maxD, grid=grid, algo=algo, npts=300)
     try:
         assert W.engine.kernel_name == "k_compare_wide2", W.engine.kernel_signature
+        assert W.engine.kernel_signature.endswith(", 2>") == ((N, maxD) in HALVED), W.engine.kernel_signature
         sel = list(range(nP))
         want, const = oracle_on_workload(W, sel, nO, algo)
         _, got = run_workload(W, 0, nO)
