@@ -999,15 +999,16 @@ static int create_impl(bioem_hip_handle *out, int device, const bioem_hip_param_
           break;
         }
     }
-    const int N1 = N / R;
     // measured against the tiled k_compare_wide (224^2): +-20 px (two 21-row tiles per axis) 15.9 vs 20.7 M/s, +-30 px
     // (three tiles) 14.8 vs 9.6, +-40 px 12.5 vs 7.2; with a T block beyond 80 KiB only one block fits a CU (256^2
     // +-40 px: 5.5 vs 6.2) -> this kernel from three tiles per axis on, while two blocks per CU fit
     // a T block that leaves one block per CU goes through LDS in two halves of the window rows where that brings the
-    // second block back (k_compare_wide2<.., HALVES = 2>: 256^2 +-40 px 6.1 on the tiled kernel, 6.7 at one block per CU)
+    // second block back (k_compare_wide2<.., HALVES = 2>: 256^2 +-40 px 6.1 on the tiled kernel, 6.7 at one block per CU,
+    // 11.1 in halves).  Halves + 16-point FFTs for a THIRD block per CU at 224^2 lose: +-40 px 12.1 vs 13.9, +-30 px 14.8 vs 17.1
     const int hrows = (rows2 / 2 + 1) & ~1;
     const bool halves2 = nblk == 2 && !small && wide2_lds_bytes(N, R, rows2, ts) > 80 * 1024 &&
                          wide2_lds_bytes(N, R, hrows, ts) <= 80 * 1024 && !getenv("BIOEM_NO_WIDE2_HALVES");
+    const int N1 = N / R;
     const int ldsRows = halves2 ? hrows : rows2;
     const bool pays = ((h->nd > 42 || ((small || small1) && (h->nd > 31 || (midWindow && !mixedLen)))) &&
                        wide2_lds_bytes(N, R, ldsRows, ts) <= 80 * 1024) ||
