@@ -360,10 +360,17 @@ fast_kernel_t wide2_kernel_r(int nblk, bool nyq, int halves)
 {
   if constexpr (R == 32)
   {
+    if (nyq && nblk == 3) // 384
+      return halves == 2 ? k_compare_wide2<32, 21, 3, true, 2> : k_compare_wide2<32, 21, 3, true>;
     if (nyq)
       return nblk == 1     ? k_compare_wide2<32, 32, 1, true>
              : halves == 2 ? k_compare_wide2<32, 21, 2, true, 2>
                            : k_compare_wide2<32, 21, 2, true>;
+  }
+  if constexpr (R == 32 || R == 16 || R == 8 || R == 30 || R == 20 || R == 12 || R == 10)
+  {
+    if (nblk == 3) // 256 < N <= 382
+      return halves == 2 ? k_compare_wide2<R, 21, 3, false, 2> : k_compare_wide2<R, 21, 3, false>;
   }
   return nblk == 1 ? k_compare_wide2<R, 32, 1, false> : halves == 2 ? k_compare_wide2<R, 21, 2, false, 2>
                                                                     : k_compare_wide2<R, 21, 2, false>;
@@ -1006,14 +1013,19 @@ static int create_impl(bioem_hip_handle *out, int device, const bioem_hip_param_
     // second block back (k_compare_wide2<.., HALVES = 2>: 256^2 +-40 px 6.1 on the tiled kernel, 6.7 at one block per CU,
     // 11.1 in halves).  Halves + 16-point FFTs for a THIRD block per CU at 224^2 lose: +-40 px 12.1 vs 13.9, +-30 px 14.8 vs 17.1
     const int hrows = (rows2 / 2 + 1) & ~1;
-    const bool halves2 = nblk == 2 && !small && wide2_lds_bytes(N, R, rows2, ts) > 80 * 1024 &&
+    // three column blocks (256 < N <= 384): 63 rows of T accumulators per wave at two waves per SIMD, against the tiled
+    // kernel 320^2 +-30 px 5.5 -> 7.4 M/s, +-40 px 4.1 -> 6.8, 288^2 +-30 px 6.0 -> 9.4, 272^2 +-40 px 4.8 -> 7.2, 384^2 +-40 px
+    // 3.1 -> 8.0; from 32 window rows on (320^2 +-20 px 7.8 -> 9.7, 288^2 8.6 -> 10.0, 300^2 7.8 -> 9.7)
+    const bool blocks3 = nblk == 3 && (R == 32 || ((R == 16 || R == 8 || R == 30 || R == 20 || R == 12 || R == 10) && !nyq)) &&
+                         !getenv("BIOEM_NO_WIDE2_BLOCKS3");
+    const bool halves2 = (nblk == 2 || blocks3) && !small && wide2_lds_bytes(N, R, rows2, ts) > 80 * 1024 &&
                          wide2_lds_bytes(N, R, hrows, ts) <= 80 * 1024 && !getenv("BIOEM_NO_WIDE2_HALVES");
     const int N1 = N / R;
     const int ldsRows = halves2 ? hrows : rows2;
-    const bool pays = ((h->nd > 42 || ((small || small1) && (h->nd > 31 || (midWindow && !mixedLen)))) &&
+    const bool pays = ((h->nd > 42 || (blocks3 && h->nd > 31) || ((small || small1) && (h->nd > 31 || (midWindow && !mixedLen)))) &&
                        wide2_lds_bytes(N, R, ldsRows, ts) <= 80 * 1024) ||
                       getenv("BIOEM_FORCE_WIDE2");
-    if (pays && nblk <= 2 && rpw <= (nblk == 1 ? 32 : 21) && N1 <= 32 && h->nd <= 128 && (!nyq || mD <= 42) &&
+    if (pays && (nblk <= 2 || blocks3) && rpw <= (nblk == 1 ? 32 : 21) && N1 <= 32 && h->nd <= 128 && (!nyq || mD <= 42) &&
         wide2_lds_bytes(N, R, ldsRows, ts) <= 160 * 1024)
     {
       h->w2Halves = halves2 ? 2 : 1;

@@ -140,10 +140,25 @@ __global__ __launch_bounds__(256, (NRW * NBLK <= 42 && R <= 16) ? 3 : 2) void k_
   unsigned long long stamp_ = __builtin_amdgcn_s_memtime();
 #endif
   // ---------------- column pass ----------------
+  const int nblk = NYQ ? (H - 1) / 64 : (H + 63) / 64;
   const int rpw = (nd + 3) >> 2; // window rows per wave
+  if (nblk > NBLK || rpw > NRW)
+  { // launched on a shape this instantiation does not cover (a dispatch error): poison the result instead of
+    // dropping columns or rows silently
+    if (threadIdx.x == 0)
+    {
+      Partial r;
+      r.sumExp = __builtin_nan("");
+      r.best = __builtin_nanf("");
+      r.id = 0;
+      r.value = 0.f;
+      r.pad = 0;
+      a.partials[(size_t) p * a.ldPart + oc] = r;
+    }
+    return;
+  }
   const int r0 = wave * rpw;
   const int nrows = max(0, min(rpw, nd - r0));
-  const int nblk = NYQ ? (H - 1) / 64 : (H + 63) / 64;
   const unsigned rowbytes = (unsigned) H * 16u;
   float Tr[NBLK][NRW], Ti[NBLK][NRW];
 #pragma unroll
@@ -174,7 +189,9 @@ __global__ __launch_bounds__(256, (NRW * NBLK <= 42 && R <= 16) ? 3 : 2) void k_
 #ifndef BIOEM_W2_FNEXT
 #define BIOEM_W2_FNEXT 0
 #endif
-  constexpr int RF = R2;
+  // particle row pairs requested at once: all R/2, or a ring of 8 where three column blocks of accumulators leave
+  // no room for 16 (k_compare_wide2<32, 21, 3>)
+  constexpr int RF = (NBLK == 3 && R2 == 16) ? 8 : R2;
   u32x4 fx[RF];
   bool fready = false;
   auto request_f = [&](int k1n, unsigned laneoffn) {
@@ -220,6 +237,9 @@ __global__ __launch_bounds__(256, (NRW * NBLK <= 42 && R <= 16) ? 3 : 2) void k_
             xi[FFT_IN(2 * k2p)] = fmaf(c.y, f.x, -(c.x * f.y));
             xr[FFT_IN(2 * k2p + 1)] = fmaf(c.z, f.z, c.w * f.w);
             xi[FFT_IN(2 * k2p + 1)] = fmaf(c.w, f.z, -(c.z * f.w));
+            if (k2p + RF < R2)
+              fx[k2p % RF] = __builtin_amdgcn_raw_buffer_load_b128(rsrcF, laneoff,
+                                                                  (unsigned) (k1 * R2 + k2p + RF) * rowbytes, 0);
             if (k2p + RC < R2)
               rc[k2p % RC] = __builtin_amdgcn_raw_buffer_load_b128(rsrcC, laneoff,
                                                                   (unsigned) (k1 * R2 + k2p + RC) * rowbytes, 0);
