@@ -408,8 +408,19 @@ fast_kernel_t wide2_kernel_small(int R, int nrw, bool nyq)
 {
   return nrw == 13 ? wide2_kernel_small_n<13>(R, nyq) : wide2_kernel_small_n<11>(R, nyq);
 }
-fast_kernel_t wide2_kernel(int R, int nblk, bool nyq, int halves = 1)
+// 22..24 rows per wave (windows of 85..96 rows: +-42 ... +-47 px) over two column blocks, 32- / 16-point FFTs
+fast_kernel_t wide2_kernel_24(int R, bool nyq, int halves)
 {
+  if (R == 32 && nyq)
+    return halves == 2 ? k_compare_wide2<32, 24, 2, true, 2> : k_compare_wide2<32, 24, 2, true>;
+  if (R == 32)
+    return halves == 2 ? k_compare_wide2<32, 24, 2, false, 2> : k_compare_wide2<32, 24, 2, false>;
+  return halves == 2 ? k_compare_wide2<16, 24, 2, false, 2> : k_compare_wide2<16, 24, 2, false>;
+}
+fast_kernel_t wide2_kernel(int R, int nblk, bool nyq, int halves = 1, int nrw = 21)
+{
+  if (nrw == 24)
+    return wide2_kernel_24(R, nyq, halves);
   switch (R)
   {
   case 32: return wide2_kernel_r<32>(nblk, nyq, halves);
@@ -527,7 +538,7 @@ int launch_compare_fold(bioem_hip_ctx *h, const BatchBuf &bb, int nOC, int orien
     const size_t lds = wide2_lds_bytes(h->N, 2 * h->fast, h->w2Rows2, h->w2TS);
     hipLaunchKernelGGL(h->w2NBLK == 1 && h->w2NRW == 21 ? wide2_kernel_small1(2 * h->fast, h->nyq)
                        : h->w2NRW <= 13                 ? wide2_kernel_small(2 * h->fast, h->w2NRW, h->nyq)
-                                                        : wide2_kernel(2 * h->fast, h->w2NBLK, h->nyq, h->w2Halves),
+                                                        : wide2_kernel(2 * h->fast, h->w2NBLK, h->nyq, h->w2Halves, h->w2NRW),
                        dim3((unsigned) ((size_t) nOC * h->nMaps)), dim3(256), lds, h->stream, aw);
   }
   else if (h->fast || h->rowsK)
@@ -1025,7 +1036,9 @@ static int create_impl(bioem_hip_handle *out, int device, const bioem_hip_param_
     const bool pays = ((h->nd > 42 || (blocks3 && h->nd > 31) || ((small || small1) && (h->nd > 31 || (midWindow && !mixedLen)))) &&
                        wide2_lds_bytes(N, R, ldsRows, ts) <= 80 * 1024) ||
                       getenv("BIOEM_FORCE_WIDE2");
-    if (pays && (nblk <= 2 || blocks3) && rpw <= (nblk == 1 ? 32 : 21) && N1 <= 32 && h->nd <= 128 && (!nyq || mD <= 42) &&
+    const bool rows24 = nblk == 2 && (R == 32 || (R == 16 && !nyq)) && rpw > 21 && rpw <= 24; // 208^2 +-42 px: 3.2 M/s tiled
+    if (pays && (nblk <= 2 || blocks3) && rpw <= (nblk == 1 ? 32 : rows24 ? 24 : 21) && N1 <= 32 && h->nd <= 128 &&
+        (!nyq || mD <= 42) &&
         wide2_lds_bytes(N, R, ldsRows, ts) <= 160 * 1024)
     {
       h->w2Halves = halves2 ? 2 : 1;
@@ -1034,7 +1047,7 @@ static int create_impl(bioem_hip_handle *out, int device, const bioem_hip_param_
       h->N1 = N1;
       h->nyq = nyq;
       h->w2NBLK = nblk;
-      h->w2NRW = nblk == 1 ? 32 : 21;
+      h->w2NRW = nblk == 1 ? 32 : rows24 ? 24 : 21;
       if (small)
         h->w2NRW = rpw <= 11 ? 11 : 13;
       if (small1)
@@ -1046,7 +1059,7 @@ static int create_impl(bioem_hip_handle *out, int device, const bioem_hip_param_
         h->winD = h->nyqWD; // sizes the Nyquist pre-kernel's tables
       HIP_CHECK(h, hipFuncSetAttribute(reinterpret_cast<const void *>(small1            ? wide2_kernel_small1(R, nyq)
                                                                      : h->w2NRW <= 13 ? wide2_kernel_small(R, h->w2NRW, nyq)
-                                                                                      : wide2_kernel(R, nblk, nyq, h->w2Halves)),
+                                                                                      : wide2_kernel(R, nblk, nyq, h->w2Halves, h->w2NRW)),
                                        hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int) wide2_lds_bytes(N, R, ldsRows, ts)));
     }
