@@ -1026,7 +1026,7 @@ static int create_impl(bioem_hip_handle *out, int device, const bioem_hip_param_
     const int hrows = (rows2 / 2 + 1) & ~1;
     // three column blocks (256 < N <= 384): 63 rows of T accumulators per wave at two waves per SIMD, against the tiled
     // kernel 320^2 +-30 px 5.5 -> 7.4 M/s, +-40 px 4.1 -> 6.8, 288^2 +-30 px 6.0 -> 9.4, 272^2 +-40 px 4.8 -> 7.2, 384^2 +-40 px
-    // 3.1 -> 8.0; from 32 window rows on (320^2 +-20 px 7.8 -> 9.7, 288^2 8.6 -> 10.0, 300^2 7.8 -> 9.7)
+    // 3.1 -> 5.7; from 32 window rows on (320^2 +-20 px 7.8 -> 9.7, 288^2 8.6 -> 10.0, 300^2 7.8 -> 9.7)
     const bool blocks3 = nblk == 3 && (R == 32 || ((R == 16 || R == 8 || R == 30 || R == 20 || R == 12 || R == 10) && !nyq)) &&
                          !getenv("BIOEM_NO_WIDE2_BLOCKS3");
     const bool halves2 = (nblk == 2 || blocks3) && !small && wide2_lds_bytes(N, R, rows2, ts) > 80 * 1024 &&
