@@ -417,8 +417,19 @@ fast_kernel_t wide2_kernel_24(int R, bool nyq, int halves)
     return halves == 2 ? k_compare_wide2<32, 24, 2, false, 2> : k_compare_wide2<32, 24, 2, false>;
   return halves == 2 ? k_compare_wide2<16, 24, 2, false, 2> : k_compare_wide2<16, 24, 2, false>;
 }
+// four column blocks (384 < N <= 512) with at most 11 rows per wave (windows of 32..44 rows), 32- / 16-point FFTs
+fast_kernel_t wide2_kernel_4(int R, bool nyq, int halves)
+{
+  if (R == 32 && nyq)
+    return halves == 2 ? k_compare_wide2<32, 11, 4, true, 2> : k_compare_wide2<32, 11, 4, true>;
+  if (R == 32)
+    return halves == 2 ? k_compare_wide2<32, 11, 4, false, 2> : k_compare_wide2<32, 11, 4, false>;
+  return halves == 2 ? k_compare_wide2<16, 11, 4, false, 2> : k_compare_wide2<16, 11, 4, false>;
+}
 fast_kernel_t wide2_kernel(int R, int nblk, bool nyq, int halves = 1, int nrw = 21)
 {
+  if (nblk == 4)
+    return wide2_kernel_4(R, nyq, halves);
   if (nrw == 24)
     return wide2_kernel_24(R, nyq, halves);
   switch (R)
@@ -435,6 +446,15 @@ fast_kernel_t wide2_kernel(int R, int nblk, bool nyq, int halves = 1, int nrw = 
   case 10: return wide2_kernel_r<10>(nblk, nyq, halves);
   default: return wide2_kernel_r<6>(nblk, nyq, halves);
   }
+}
+// the instantiation for a selection (create sets the attributes of the SAME function the launch uses)
+fast_kernel_t wide2_pick(int R, int nrw, int nblk, bool nyq, int halves)
+{
+  if (nblk == 1 && nrw == 21)
+    return wide2_kernel_small1(R, nyq);
+  if (nblk == 2 && nrw <= 13)
+    return wide2_kernel_small(R, nrw, nyq);
+  return wide2_kernel(R, nblk, nyq, halves, nrw);
 }
 size_t wide2_lds_bytes(int N, int R, int rows2, int ts)
 { // tables (twiddles, visiting ranks, log table, wave results, posterior constants) + max(four FFT-output slots, T block)
@@ -536,10 +556,7 @@ int launch_compare_fold(bioem_hip_ctx *h, const BatchBuf &bb, int nOC, int orien
         hipLaunchKernelGGL(k_nyquist_rows<42>, gridq, dim3(256), 0, h->stream, aw);
     }
     const size_t lds = wide2_lds_bytes(h->N, 2 * h->fast, h->w2Rows2, h->w2TS);
-    hipLaunchKernelGGL(h->w2NBLK == 1 && h->w2NRW == 21 ? wide2_kernel_small1(2 * h->fast, h->nyq)
-                       : h->w2NRW <= 13                 ? wide2_kernel_small(2 * h->fast, h->w2NRW, h->nyq)
-                                                        : wide2_kernel(2 * h->fast, h->w2NBLK, h->nyq, h->w2Halves, h->w2NRW),
-                       dim3((unsigned) ((size_t) nOC * h->nMaps)), dim3(256), lds, h->stream, aw);
+    hipLaunchKernelGGL(wide2_pick(2 * h->fast, h->w2NRW, h->w2NBLK, h->nyq, h->w2Halves), dim3((unsigned) ((size_t) nOC * h->nMaps)), dim3(256), lds, h->stream, aw);
   }
   else if (h->fast || h->rowsK)
   {
@@ -1029,15 +1046,17 @@ static int create_impl(bioem_hip_handle *out, int device, const bioem_hip_param_
     // 3.1 -> 5.7; from 32 window rows on (320^2 +-20 px 7.8 -> 9.7, 288^2 8.6 -> 10.0, 300^2 7.8 -> 9.7)
     const bool blocks3 = nblk == 3 && (R == 32 || ((R == 16 || R == 8 || R == 30 || R == 20 || R == 12 || R == 10) && !nyq)) &&
                          !getenv("BIOEM_NO_WIDE2_BLOCKS3");
-    const bool halves2 = (nblk == 2 || blocks3) && !small && wide2_lds_bytes(N, R, rows2, ts) > 80 * 1024 &&
+    const bool blocks4 = nblk == 4 && (R == 32 || (R == 16 && !nyq)) && rpw <= 11 && h->nd > 31 &&
+                         !getenv("BIOEM_NO_WIDE2_BLOCKS4");
+    const bool halves2 = (nblk == 2 || blocks3 || blocks4) && !small && wide2_lds_bytes(N, R, rows2, ts) > 80 * 1024 &&
                          wide2_lds_bytes(N, R, hrows, ts) <= 80 * 1024 && !getenv("BIOEM_NO_WIDE2_HALVES");
     const int N1 = N / R;
     const int ldsRows = halves2 ? hrows : rows2;
-    const bool pays = ((h->nd > 42 || (blocks3 && h->nd > 31) || ((small || small1) && (h->nd > 31 || (midWindow && !mixedLen)))) &&
+    const bool pays = ((h->nd > 42 || ((blocks3 || blocks4) && h->nd > 31) || ((small || small1) && (h->nd > 31 || (midWindow && !mixedLen)))) &&
                        wide2_lds_bytes(N, R, ldsRows, ts) <= 80 * 1024) ||
                       getenv("BIOEM_FORCE_WIDE2");
     const bool rows24 = nblk == 2 && (R == 32 || (R == 16 && !nyq)) && rpw > 21 && rpw <= 24; // 208^2 +-42 px: 3.2 M/s tiled
-    if (pays && (nblk <= 2 || blocks3) && rpw <= (nblk == 1 ? 32 : rows24 ? 24 : 21) && N1 <= 32 && h->nd <= 128 &&
+    if (pays && (nblk <= 2 || blocks3 || blocks4) && rpw <= (nblk == 1 ? 32 : rows24 ? 24 : 21) && N1 <= 32 && h->nd <= 128 &&
         (!nyq || mD <= 42) &&
         wide2_lds_bytes(N, R, ldsRows, ts) <= 160 * 1024)
     {
@@ -1047,7 +1066,7 @@ static int create_impl(bioem_hip_handle *out, int device, const bioem_hip_param_
       h->N1 = N1;
       h->nyq = nyq;
       h->w2NBLK = nblk;
-      h->w2NRW = nblk == 1 ? 32 : rows24 ? 24 : 21;
+      h->w2NRW = nblk == 1 ? 32 : rows24 ? 24 : blocks4 ? 11 : 21;
       if (small)
         h->w2NRW = rpw <= 11 ? 11 : 13;
       if (small1)
@@ -1057,9 +1076,7 @@ static int create_impl(bioem_hip_handle *out, int device, const bioem_hip_param_
       h->nyqWD = mD <= 20 ? 20 : mD <= 31 ? 31 : 42;
       if (nyq)
         h->winD = h->nyqWD; // sizes the Nyquist pre-kernel's tables
-      HIP_CHECK(h, hipFuncSetAttribute(reinterpret_cast<const void *>(small1            ? wide2_kernel_small1(R, nyq)
-                                                                     : h->w2NRW <= 13 ? wide2_kernel_small(R, h->w2NRW, nyq)
-                                                                                      : wide2_kernel(R, nblk, nyq, h->w2Halves, h->w2NRW)),
+      HIP_CHECK(h, hipFuncSetAttribute(reinterpret_cast<const void *>(wide2_pick(R, h->w2NRW, nblk, nyq, h->w2Halves)),
                                        hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int) wide2_lds_bytes(N, R, ldsRows, ts)));
     }

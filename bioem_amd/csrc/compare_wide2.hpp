@@ -191,7 +191,7 @@ __global__ __launch_bounds__(256, (NRW * NBLK <= 42 && R <= 16) ? 3 : 2) void k_
 #endif
   // particle row pairs requested at once: all R/2, or a ring of 8 where three column blocks of accumulators leave
   // no room for 16 (k_compare_wide2<32, 21, 3>)
-  constexpr int RF = (NBLK == 3 && R2 == 16) ? 8 : R2;
+  constexpr int RF = (NBLK >= 3 && R2 == 16) ? 8 : R2;
   u32x4 fx[RF];
   bool fready = false;
   auto request_f = [&](int k1n, unsigned laneoffn) {

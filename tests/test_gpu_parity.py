@@ -807,7 +807,7 @@ def test_image_sizes_against_oracle(N, maxD, grid, fast, algo):
 
 
 HALVED = {(256, 40), (240, 38), (250, 40), (256, 37), (248, 78), (320, 40), (272, 40), (360, 40), (264, 35), (384, 40),
-          (380, 80), (300, 30), (224, 47), (256, 42), (208, 42)}   # sizes of the list below that take HALVES = 2
+          (380, 80), (300, 30), (224, 47), (256, 42), (208, 42), (448, 20), (512, 20), (432, 42)}   # sizes of the list below that take HALVES = 2
 
 
 # k_compare_wide2 (shared column transforms + row FFT) is picked from three 21-row tiles per axis on; forced here for
@@ -831,7 +831,9 @@ HALVED = {(256, 40), (240, 38), (250, 40), (256, 37), (248, 78), (320, 40), (272
                                          (320, 40, 1), (288, 25, 1), (272, 40, 1), (300, 30, 1), (360, 40, 1), (280, 27, 1),
                                          (264, 35, 1), (290, 22, 1), (384, 40, 1), (384, 20, 1), (380, 80, 2),
                                          # 22..24 rows per wave over two column blocks
-                                         (208, 42, 1), (224, 47, 1), (256, 42, 1), (192, 88, 2)])
+                                         (208, 42, 1), (224, 47, 1), (256, 42, 1), (192, 88, 2),
+                                         # four column blocks (384 < N <= 512), at most 11 rows per wave
+                                         (448, 20, 1), (512, 20, 1), (400, 18, 1), (512, 16, 1), (432, 42, 2)])
 @pytest.mark.parametrize("algo", [1, 2])
 def test_wide2_kernel_against_oracle(N, maxD, grid, algo, monkeypatch):
     from bioem_amd.synthetic import Workload
