@@ -109,7 +109,7 @@ struct bioem_hip_ctx
   // k_compare_wide2 (compare_wide2.hpp): wide window in ONE launch per batch -- column transforms shared by the four
   // waves of a comparison, row FFT
   bool wide2 = false;
-  int w2NRW = 0, w2NBLK = 0, w2TS = 0, w2Rows2 = 0, nyqWD = 0, w2Halves = 1;
+  int w2NRW = 0, w2NBLK = 0, w2TS = 0, w2Rows2 = 0, nyqWD = 0, w2Halves = 1, w2NW = 4;
   float2 *dTwk2 = nullptr; // [N1][nd] recombination twiddles exp(2 pi i dx k1 / N), rows in sorted order
   float2 *dConvShift = nullptr;
   Partial *dPartTiles = nullptr;
@@ -448,18 +448,33 @@ fast_kernel_t wide2_kernel(int R, int nblk, bool nyq, int halves = 1, int nrw = 
   }
 }
 // the instantiation for a selection (create sets the attributes of the SAME function the launch uses)
-fast_kernel_t wide2_pick(int R, int nrw, int nblk, bool nyq, int halves)
+// eight waves per comparison: 16- / 12- / 10- / 8-point FFTs, 11 rows per wave, two column blocks, whole T block
+fast_kernel_t wide2_kernel_w8(int R, bool nyq)
 {
+  if (nyq)
+    return k_compare_wide2<16, 11, 2, true, 1, 8>;
+  switch (R)
+  {
+  case 12: return k_compare_wide2<12, 11, 2, false, 1, 8>;
+  case 10: return k_compare_wide2<10, 11, 2, false, 1, 8>;
+  case 8: return k_compare_wide2<8, 11, 2, false, 1, 8>;
+  default: return k_compare_wide2<16, 11, 2, false, 1, 8>;
+  }
+}
+fast_kernel_t wide2_pick(int R, int nrw, int nblk, bool nyq, int halves, int nw = 4)
+{
+  if (nw == 8)
+    return wide2_kernel_w8(R, nyq);
   if (nblk == 1 && nrw == 21)
     return wide2_kernel_small1(R, nyq);
   if (nblk == 2 && nrw <= 13)
     return wide2_kernel_small(R, nrw, nyq);
   return wide2_kernel(R, nblk, nyq, halves, nrw);
 }
-size_t wide2_lds_bytes(int N, int R, int rows2, int ts)
-{ // tables (twiddles, visiting ranks, log table, wave results, posterior constants) + max(four FFT-output slots, T block)
-  const size_t slots = (size_t) 4 * R * 64 * 8, tblock = (size_t) rows2 * ts * 8;
-  return (size_t) ((N + 2) & ~1) * 8 + 512 + 1024 + 192 + std::max(slots, tblock);
+size_t wide2_lds_bytes(int N, int R, int rows2, int ts, int nw = 4)
+{ // tables (twiddles, visiting ranks, log table, wave results, posterior constants) + max(one FFT-output slot per wave, T block)
+  const size_t slots = (size_t) nw * R * 64 * 8, tblock = (size_t) rows2 * ts * 8;
+  return (size_t) ((N + 2) & ~1) * 8 + 512 + 1024 + 256 + std::max(slots, tblock);
 }
 
 template <int WD>
@@ -555,8 +570,9 @@ int launch_compare_fold(bioem_hip_ctx *h, const BatchBuf &bb, int nOC, int orien
       else
         hipLaunchKernelGGL(k_nyquist_rows<42>, gridq, dim3(256), 0, h->stream, aw);
     }
-    const size_t lds = wide2_lds_bytes(h->N, 2 * h->fast, h->w2Rows2, h->w2TS);
-    hipLaunchKernelGGL(wide2_pick(2 * h->fast, h->w2NRW, h->w2NBLK, h->nyq, h->w2Halves), dim3((unsigned) ((size_t) nOC * h->nMaps)), dim3(256), lds, h->stream, aw);
+    const size_t lds = wide2_lds_bytes(h->N, 2 * h->fast, h->w2Rows2, h->w2TS, h->w2NW);
+    hipLaunchKernelGGL(wide2_pick(2 * h->fast, h->w2NRW, h->w2NBLK, h->nyq, h->w2Halves, h->w2NW),
+                       dim3((unsigned) ((size_t) nOC * h->nMaps)), dim3(64 * h->w2NW), lds, h->stream, aw);
   }
   else if (h->fast || h->rowsK)
   {
@@ -1076,9 +1092,35 @@ static int create_impl(bioem_hip_handle *out, int device, const bioem_hip_param_
       h->nyqWD = mD <= 20 ? 20 : mD <= 31 ? 31 : 42;
       if (nyq)
         h->winD = h->nyqWD; // sizes the Nyquist pre-kernel's tables
-      HIP_CHECK(h, hipFuncSetAttribute(reinterpret_cast<const void *>(wide2_pick(R, h->w2NRW, nblk, nyq, h->w2Halves)),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int) wide2_lds_bytes(N, R, ldsRows, ts)));
+      int ldsFinal = (int) wide2_lds_bytes(N, R, ldsRows, ts);
+      // eight waves per comparison (512-thread blocks, `k_compare_wide2<.., NW = 8>`): 11 rows per wave over two column
+      // blocks with a 16- / 12- / 10- / 8-point FFT -- 110 registers, four waves per SIMD at two blocks per CU.  It wins
+      // where the four-wave kernel of that length is held to two blocks per CU by its T block (208^2 +-30 px 14.5 ->
+      // 17.7 M/s, +-40 px 11.8 -> 14.1, 240^2 +-30 px 13.4 -> 16.0, 176^2 +-40 px 13.4 -> 15.2, 144^2 +-40 px 14.7 -> 17.4) and
+      // loses against three blocks per CU (176^2 +-30 px 22.9 vs 19.1), against the 32-point two-wave kernel (224^2 +-40 px
+      // 13.8 vs 13.4) and with the T block in halves (240^2 +-40 px 11.8 vs 9.5: spills under the 128-register cap)
+      {
+        int r8 = 0;
+        if (const char *f8 = getenv("BIOEM_W2_W8"))
+          r8 = atoi(f8); // experiments: force a length (16, 12, 10, 8)
+        else if ((R == 16 || R == 10) && !nyq && !getenv("BIOEM_NO_WIDE2_W8"))
+          r8 = R; // (250^2 +-30 px 10.2 -> 12.1 with 10 points; 200^2 keeps its 20-point two-wave kernel: 15.3 vs 14.4)
+        const bool ok8 = (r8 == 16 || ((r8 == 12 || r8 == 10 || r8 == 8) && !nyq)) && N % r8 == 0 && N / r8 <= 32;
+        if (ok8 && nblk == 2 && !small && h->w2Halves == 1 && (h->nd + 7) / 8 <= 11 &&
+            wide2_lds_bytes(N, r8, rows2, ts, 4) > 160 * 1024 / 3 && wide2_lds_bytes(N, r8, rows2, ts, 8) <= 80 * 1024)
+        {
+          R = r8;
+          h->w2NW = 8;
+          h->fast = r8 / 2;
+          h->N1 = N / r8;
+          h->w2NRW = 11;
+          h->w2Rows2 = rows2;
+          ldsFinal = (int) wide2_lds_bytes(N, r8, rows2, ts, 8);
+        }
+      }
+      HIP_CHECK(h, hipFuncSetAttribute(reinterpret_cast<const void *>(
+                                           wide2_pick(R, h->w2NRW, nblk, nyq, h->w2Halves, h->w2NW)),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, ldsFinal));
     }
   }
   if (!h->wide2 && N >= 8 && (mD > 15 || h->nd > 31) && h->nd == 2 * mD + 1 && !getenv("BIOEM_NO_TILES"))
@@ -1294,10 +1336,10 @@ static int create_impl(bioem_hip_handle *out, int device, const bioem_hip_param_
   if (h->wide2)
   { // recombination twiddles exp(2 pi i dx k1 / N), dx = (m - mD) gs, laid out per (k1, wave): the NRW window rows a
     // wave folds are contiguous (rows beyond the window: zero)
-    const int NRW = h->w2NRW, rpw = (h->nd + 3) / 4;
-    std::vector<float2> t2((size_t) h->N1 * 4 * NRW, make_float2(0.f, 0.f));
+    const int NRW = h->w2NRW, NWV = h->w2NW, rpw = (h->nd + NWV - 1) / NWV;
+    std::vector<float2> t2((size_t) h->N1 * NWV * NRW, make_float2(0.f, 0.f));
     for (int k1 = 0; k1 < h->N1; k1++)
-      for (int w = 0; w < 4; w++)
+      for (int w = 0; w < NWV; w++)
         for (int d = 0; d < NRW; d++)
         {
           const int m = w * rpw + d;
@@ -1305,7 +1347,7 @@ static int create_impl(bioem_hip_handle *out, int device, const bioem_hip_param_
             continue;
           const long long dx = (long long) (m - mD) * h->gs;
           const double ang = 2.0 * M_PI * (double) (((dx * k1) % N + N) % N) / (double) N;
-          t2[((size_t) k1 * 4 + w) * NRW + d] = make_float2((float) cos(ang), (float) sin(ang));
+          t2[((size_t) k1 * NWV + w) * NRW + d] = make_float2((float) cos(ang), (float) sin(ang));
         }
     HIP_CHECK(h, hipMalloc(&h->dTwk2, sizeof(float2) * t2.size()));
     HIP_CHECK(h, hipMemcpy(h->dTwk2, t2.data(), sizeof(float2) * t2.size(), hipMemcpyHostToDevice));
@@ -2105,9 +2147,11 @@ const char *bioem_hip_kernel_signature(bioem_hip_handle h)
   const char *nq = h->nyq ? "true" : "false";
   if (h->wide2)
     if (h->w2Halves == 2)
-      snprintf(buf, sizeof(buf), "k_compare_wide2<%d, %d, %d, %s, 2>", 2 * h->fast, h->w2NRW, h->w2NBLK, nq);
+      snprintf(buf, sizeof(buf), h->w2NW == 8 ? "k_compare_wide2<%d, %d, %d, %s, 2, 8>" : "k_compare_wide2<%d, %d, %d, %s, 2>",
+               2 * h->fast, h->w2NRW, h->w2NBLK, nq);
     else
-      snprintf(buf, sizeof(buf), "k_compare_wide2<%d, %d, %d, %s>", 2 * h->fast, h->w2NRW, h->w2NBLK, nq);
+      snprintf(buf, sizeof(buf), h->w2NW == 8 ? "k_compare_wide2<%d, %d, %d, %s, 1, 8>" : "k_compare_wide2<%d, %d, %d, %s>",
+               2 * h->fast, h->w2NRW, h->w2NBLK, nq);
   else if (h->fast && h->tileT && h->wideWPC)
     snprintf(buf, sizeof(buf), "k_compare_wide<%d, %d, %d, %s>", 2 * h->fast, h->gs, h->wideWPC, nq);
   else if (h->fast)

@@ -57,8 +57,12 @@ __device__ __forceinline__ const_float2_ptr as_constant(const float2 *p)
 
 // HALVES = 2: the T block goes through LDS in two halves of the window rows (row pass + posterior per half), for the
 // sizes whose whole T block would leave one block per CU (240^2 ... 256^2 at +-35 ... +-42 px)
-template <int R, int NRW, int NBLK, bool NYQ, int HALVES = 1>
-__global__ __launch_bounds__(256, (NRW * NBLK <= 42 && R <= 16) ? 3 : 2) void k_compare_wide2(const CompareArgs a)
+// NW = 8: eight waves per comparison (512-thread blocks) -- half the window rows per wave, so that the 16-point
+// instantiation with 11 rows per wave (110 registers) covers windows of up to 88 rows at FOUR waves per SIMD with two
+// blocks per CU, and larger images / windows keep a register-sized share per wave
+template <int R, int NRW, int NBLK, bool NYQ, int HALVES = 1, int NW = 4>
+__global__ __launch_bounds__(64 * NW, NW == 8 ? ((NRW * NBLK <= 26 && R <= 16) ? 4 : 2)
+                                               : ((NRW * NBLK <= 42 && R <= 16) ? 3 : 2)) void k_compare_wide2(const CompareArgs a)
 {
   constexpr int R2 = R / 2;
   // depth of the operand ring (divides R2): the first RD row pairs of a wave's next step are issued before the
@@ -83,9 +87,10 @@ __global__ __launch_bounds__(256, (NRW * NBLK <= 42 && R <= 16) ? 3 : 2) void k_
   float2 *twl = reinterpret_cast<float2 *>(smem);
   int *dinv = reinterpret_cast<int *>(smem + (size_t) ((N + 2) & ~1) * 8);                 // nd ints (512 B reserved)
   double2 *ltab = reinterpret_cast<double2 *>(smem + (size_t) ((N + 2) & ~1) * 8 + 512);    // 64 entries
-  LseF *lsew = reinterpret_cast<LseF *>(smem + (size_t) ((N + 2) & ~1) * 8 + 512 + 1024);   // 4 wave results (128 B)
-  PostConst *cst = reinterpret_cast<PostConst *>(smem + (size_t) ((N + 2) & ~1) * 8 + 512 + 1024 + 128); // 64 B
-  float2 *U = reinterpret_cast<float2 *>(smem + (size_t) ((N + 2) & ~1) * 8 + 512 + 1024 + 192);
+  // wave results (NW x 24 B) and posterior constants (48 B) share 256 B
+  LseF *lsew = reinterpret_cast<LseF *>(smem + (size_t) ((N + 2) & ~1) * 8 + 512 + 1024);
+  PostConst *cst = reinterpret_cast<PostConst *>(smem + (size_t) ((N + 2) & ~1) * 8 + 512 + 1024 + 192);
+  float2 *U = reinterpret_cast<float2 *>(smem + (size_t) ((N + 2) & ~1) * 8 + 512 + 1024 + 256);
   const int wave = __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6));
   const int lane = threadIdx.x & 63;
   const int gs = a.gs, mD = a.maxD / gs;
@@ -141,7 +146,7 @@ __global__ __launch_bounds__(256, (NRW * NBLK <= 42 && R <= 16) ? 3 : 2) void k_
 #endif
   // ---------------- column pass ----------------
   const int nblk = NYQ ? (H - 1) / 64 : (H + 63) / 64;
-  const int rpw = (nd + 3) >> 2; // window rows per wave
+  const int rpw = (nd + NW - 1) / NW; // window rows per wave
   if (nblk > NBLK || rpw > NRW)
   { // launched on a shape this instantiation does not cover (a dispatch error): poison the result instead of
     // dropping columns or rows silently
@@ -208,7 +213,7 @@ __global__ __launch_bounds__(256, (NRW * NBLK <= 42 && R <= 16) ? 3 : 2) void k_
       const unsigned laneoff = (unsigned) (ky < H ? ky : H - 1) * 16u;
       const int kyn = ky + 64;
       const unsigned laneoff_next = (unsigned) (kyn < H ? kyn : H - 1) * 16u;
-      for (int base = 0; base < N1; base += 4)
+      for (int base = 0; base < N1; base += NW)
       {
         const int k1 = base + wave;
         if (k1 < N1)
@@ -254,9 +259,9 @@ __global__ __launch_bounds__(256, (NRW * NBLK <= 42 && R <= 16) ? 3 : 2) void k_
             slot[n * 64] = make_float2(xr[FFT_OUT(n)], xi[FFT_OUT(n)]);
           // next step of this wave: same block four k1 further, or the first one of the next column block
           fready = false;
-          if (BIOEM_W2_FNEXT && k1 + 4 < N1)
+          if (BIOEM_W2_FNEXT && k1 + NW < N1)
           {
-            request_f(k1 + 4, laneoff);
+            request_f(k1 + NW, laneoff);
             fready = true;
           }
           else if (BIOEM_W2_FNEXT && blk + 1 < nblk && wave < N1)
@@ -271,13 +276,13 @@ __global__ __launch_bounds__(256, (NRW * NBLK <= 42 && R <= 16) ? 3 : 2) void k_
         // fold the round's slots into this wave's rows:  T[dx] += w_N^(dx k1) * y_k1[dx mod R]
         // (all NRW accumulators; rows beyond this wave's share fold zeros and are never stored)
 #pragma unroll
-        for (int s = 0; s < 4; s++)
+        for (int s = 0; s < NW; s++)
         {
           const int k1s = base + s;
           if (k1s < N1)
           {
             // this wave's NRW twiddles of step k1s are contiguous: a few wide scalar loads
-            const const_float2_ptr twk = as_constant(a.twk) + ((size_t) k1s * 4 + wave) * NRW;
+            const const_float2_ptr twk = as_constant(a.twk) + ((size_t) k1s * NW + wave) * NRW;
             const float2 *ys = U + (size_t) s * R * 64;
 #ifndef BIOEM_W2_FOLD_CHUNK
 #define BIOEM_W2_FOLD_CHUNK 7
@@ -357,7 +362,7 @@ __global__ __launch_bounds__(256, (NRW * NBLK <= 42 && R <= 16) ? 3 : 2) void k_
     const float *tq = a.tnyq + ((size_t) p * a.ldPart + oc) * NWQ;
     Tl[(size_t) (r0 + lane - h0) * TS + N / 2] = make_float2(tq[r0 + lane - mD + a.nyqWD], 0.f);
   }
-  if ((nd & 1) && wave == 3 && nd >= h0 && nd < h1)
+  if ((nd & 1) && wave == NW - 1 && nd >= h0 && nd < h1)
     for (int c = lane; c < H; c += 64) // odd row count: the last pair's second row is empty
       Tl[(size_t) (nd - h0) * TS + c] = make_float2(0.f, 0.f);
   __syncthreads();
@@ -365,7 +370,7 @@ __global__ __launch_bounds__(256, (NRW * NBLK <= 42 && R <= 16) ? 3 : 2) void k_
   W2_STAMP(1);
   // ---------------- row pass: pairs of rows, private to a wave ----------------
   const int npairs = (h1 - h0) >> 1;
-  const int ppw = (npairs + 3) >> 2;
+  const int ppw = (npairs + NW - 1) / NW;
   const int pj0 = wave * ppw;
   const int npw = max(0, min(ppw, npairs - pj0));
   const int PPP = 64 / N1; // pairs per pass
@@ -540,7 +545,7 @@ __global__ __launch_bounds__(256, (NRW * NBLK <= 42 && R <= 16) ? 3 : 2) void k_
   if (threadIdx.x == 0)
   {
     LseF Z = lsew[0];
-    for (int w = 1; w < 4; w++)
+    for (int w = 1; w < NW; w++)
     {
       const LseF o = lsew[w];
       if (o.m > Z.m || (o.m == Z.m && o.id < Z.id))
