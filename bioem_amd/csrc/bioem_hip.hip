@@ -461,8 +461,19 @@ fast_kernel_t wide2_kernel_w8(int R, bool nyq)
   default: return k_compare_wide2<16, 11, 2, false, 1, 8>;
   }
 }
+// ... over four column blocks (384 < N <= 512), windows of 45..88 rows: one 512-thread block per CU
+fast_kernel_t wide2_kernel_w8_4(int R, bool nyq, int halves)
+{
+  if (R == 32 && nyq)
+    return halves == 2 ? k_compare_wide2<32, 11, 4, true, 2, 8> : k_compare_wide2<32, 11, 4, true, 1, 8>;
+  if (R == 32)
+    return halves == 2 ? k_compare_wide2<32, 11, 4, false, 2, 8> : k_compare_wide2<32, 11, 4, false, 1, 8>;
+  return halves == 2 ? k_compare_wide2<16, 11, 4, false, 2, 8> : k_compare_wide2<16, 11, 4, false, 1, 8>;
+}
 fast_kernel_t wide2_pick(int R, int nrw, int nblk, bool nyq, int halves, int nw = 4)
 {
+  if (nw == 8 && nblk == 4)
+    return wide2_kernel_w8_4(R, nyq, halves);
   if (nw == 8)
     return wide2_kernel_w8(R, nyq);
   if (nblk == 1 && nrw == 21)
@@ -1121,6 +1132,45 @@ static int create_impl(bioem_hip_handle *out, int device, const bioem_hip_param_
       HIP_CHECK(h, hipFuncSetAttribute(reinterpret_cast<const void *>(
                                            wide2_pick(R, h->w2NRW, nblk, nyq, h->w2Halves, h->w2NW)),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, ldsFinal));
+    }
+  }
+  // four column blocks with 45..88 window rows: eight waves per comparison, one 512-thread block per CU (T block whole
+  // or in halves within 160 KiB) -- the tiled kernel runs 512^2 +-40 px at 1.7 M/s
+  if (!h->wide2 && N % 2 == 0 && h->nd == 2 * mD + 1 && h->nd > 44 && (h->nd + 7) / 8 <= 11 && !getenv("BIOEM_NO_WIDE2") &&
+      !getenv("BIOEM_NO_WIDE2_BLOCKS4"))
+  {
+    const bool nyq = BIOEM_NYQUIST_SPLIT && (N / 2) % 64 == 0;
+    const int nblk = nyq ? (h->H - 1) / 64 : (h->H + 63) / 64;
+    const int R = (N % 32 == 0) ? 32 : (N % 16 == 0 && !nyq) ? 16 : 0;
+    const int rows2 = 2 * ((h->nd + 1) / 2), hrows = (rows2 / 2 + 1) & ~1;
+    int ts = h->H;
+    while (ts % 16 != 4)
+      ts++;
+    // (measured: 512^2 +-40 px 1.67 -> 2.28 M/s, +-30 px 2.11 -> 2.96, 448^2 +-40 px 2.48 -> 3.71; with 16 points 400^2 +-40 px
+    // 2.80 -> 3.11 but +-30 px 3.74 -> 3.42: from 71 rows on there)
+    if (nblk == 4 && R && (R == 32 || h->nd > 70) && N / R <= 32 && (!nyq || mD <= 42))
+    {
+      const bool full = wide2_lds_bytes(N, R, rows2, ts, 8) <= 160 * 1024;
+      const bool half = !full && wide2_lds_bytes(N, R, hrows, ts, 8) <= 160 * 1024;
+      if (full || half)
+      {
+        h->wide2 = true;
+        h->w2NW = 8;
+        h->w2Halves = half ? 2 : 1;
+        h->fast = R / 2;
+        h->N1 = N / R;
+        h->nyq = nyq;
+        h->w2NBLK = 4;
+        h->w2NRW = 11;
+        h->w2TS = ts;
+        h->w2Rows2 = half ? hrows : rows2;
+        h->nyqWD = mD <= 20 ? 20 : mD <= 31 ? 31 : 42;
+        if (nyq)
+          h->winD = h->nyqWD;
+        HIP_CHECK(h, hipFuncSetAttribute(reinterpret_cast<const void *>(wide2_pick(R, 11, 4, nyq, h->w2Halves, 8)),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         (int) wide2_lds_bytes(N, R, h->w2Rows2, ts, 8)));
+      }
     }
   }
   if (!h->wide2 && N >= 8 && (mD > 15 || h->nd > 31) && h->nd == 2 * mD + 1 && !getenv("BIOEM_NO_TILES"))

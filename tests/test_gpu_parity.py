@@ -806,9 +806,9 @@ def test_image_sizes_against_oracle(N, maxD, grid, fast, algo):
         W.engine.close()
 
 
-EIGHT_WAVES = {(208, 30), (240, 34), (176, 40), (144, 43), (250, 30), (240, 64)}   # ... that run eight waves per comparison
+EIGHT_WAVES = {(208, 30), (240, 34), (176, 40), (144, 43), (250, 30), (240, 64), (512, 40), (448, 30), (400, 43), (512, 23)}   # ... that run eight waves per comparison
 HALVED = {(256, 40), (240, 38), (250, 40), (256, 37), (248, 78), (320, 40), (272, 40), (360, 40), (264, 35), (384, 40),
-          (380, 80), (300, 30), (224, 47), (256, 42), (208, 42), (448, 20), (512, 20), (432, 42)}   # sizes of the list below that take HALVES = 2
+          (380, 80), (300, 30), (224, 47), (256, 42), (208, 42), (448, 20), (512, 20), (432, 42), (512, 40)}   # sizes of the list below that take HALVES = 2
 
 
 # k_compare_wide2 (shared column transforms + row FFT) is picked from three 21-row tiles per axis on; forced here for
@@ -836,7 +836,9 @@ HALVED = {(256, 40), (240, 38), (250, 40), (256, 37), (248, 78), (320, 40), (272
                                          # four column blocks (384 < N <= 512), at most 11 rows per wave
                                          (448, 20, 1), (512, 20, 1), (400, 18, 1), (512, 16, 1), (432, 42, 2),
                                          # eight waves per comparison (16- / 10-point FFTs, two blocks per CU)
-                                         (208, 30, 1), (240, 34, 1), (176, 40, 1), (144, 43, 1), (250, 30, 1), (240, 64, 2)])
+                                         (208, 30, 1), (240, 34, 1), (176, 40, 1), (144, 43, 1), (250, 30, 1), (240, 64, 2),
+                                         # ... over four column blocks
+                                         (512, 40, 1), (448, 30, 1), (400, 43, 1), (512, 23, 1)])
 @pytest.mark.parametrize("algo", [1, 2])
 def test_wide2_kernel_against_oracle(N, maxD, grid, algo, monkeypatch):
     from bioem_amd.synthetic import Workload
@@ -845,8 +847,9 @@ def test_wide2_kernel_against_oracle(N, maxD, grid, algo, monkeypatch):
     W = Workload(N=N, nP=nP, nOrient=nO, nEnv=2, maxD=maxD, grid=grid, algo=algo, npts=300)
     try:
         assert W.engine.kernel_name == "k_compare_wide2", W.engine.kernel_signature
-        assert W.engine.kernel_signature.endswith(", 2>") == ((N, maxD) in HALVED), W.engine.kernel_signature
-        assert W.engine.kernel_signature.endswith(", 1, 8>") == ((N, maxD) in EIGHT_WAVES), W.engine.kernel_signature
+        assert (", 2>" in W.engine.kernel_signature or ", 2, 8>" in W.engine.kernel_signature) == ((N, maxD) in HALVED), \
+            W.engine.kernel_signature
+        assert W.engine.kernel_signature.endswith(", 8>") == ((N, maxD) in EIGHT_WAVES), W.engine.kernel_signature
         sel = list(range(nP))
         want, const = oracle_on_workload(W, sel, nO, algo)
         _, got = run_workload(W, 0, nO)
