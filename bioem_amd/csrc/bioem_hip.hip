@@ -1240,6 +1240,12 @@ static int create_impl(bioem_hip_handle *out, int device, const bioem_hip_param_
   {
     h->N1 = h->fast ? N / (2 * h->fast) : 0;
     h->nyq = BIOEM_NYQUIST_SPLIT && h->fast && (N / 2) % 64 == 0;
+    // 11-row windows: with four column blocks and a length <= 16 (or 40+ column steps) the 21-row template is the faster
+    // one (+-5 px: 432^2 11.0 -> 13.0 M/s, 360^2 16.7 -> 19.2, 400^2 13.5 -> 14.7; with 32 points 448^2 / 512^2 tie; up to
+    // 336^2 and at 384^2 the 11-row template wins by 7-25 %)
+    const int nblkF = h->nyq ? (h->H - 1) / 64 : (h->H + 63) / 64;
+    if (h->fast && h->winD == 5 && !h->tileT && ((nblkF >= 4 && h->fast <= 8) || h->N1 >= 40) && !getenv("BIOEM_KEEP_WD5"))
+      h->winD = 10;
   }
   // no even factor (odd N) but a window of at most 31 rows: k_compare_rows (reference layout, direct column sums,
   // the fast kernel's T exchange / window / posterior) instead of the generic kernel

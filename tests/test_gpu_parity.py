@@ -790,7 +790,9 @@ def test_config5_shape_two_shards_device_top_k(tmp_path):
                                               (33, 4, 1, 0), (129, 20, 2, 0), (9, 2, 1, 0), (125, 40, 1, 0), (75, 16, 1, 0),
                                               # small windows: the 11-row template (rows <= +-5)
                                               (224, 5, 1, 1), (128, 10, 2, 1), (64, 0, 1, 1), (96, 20, 4, 1),
-                                              (80, 4, 2, 1), (224, 10, 2, 1)])
+                                              (80, 4, 2, 1), (224, 10, 2, 1),
+                                              # ... which the largest sizes run on the 21-row template
+                                              (400, 5, 1, 1), (360, 4, 1, 1)])
 @pytest.mark.parametrize("algo", [1, 2])
 def test_image_sizes_against_oracle(N, maxD, grid, fast, algo):
     from bioem_amd.synthetic import Workload
