@@ -306,7 +306,7 @@ __global__ void k_convolve(const float2 *__restrict__ proj, const float2 *__rest
                            float2 *__restrict__ conv, float *__restrict__ scratch,
                            bioem_hip_param5 *__restrict__ params)
 {
-  __shared__ float buf[4096];
+  __shared__ __align__(16) float buf[2][4096];
   const int c = c0 + blockIdx.x, ob = blockIdx.y;
   const int oc = ob * gridDim.x + blockIdx.x;
   const int M = N * H;
@@ -340,16 +340,42 @@ __global__ void k_convolve(const float2 *__restrict__ proj, const float2 *__rest
   }
   __syncthreads();
   __threadfence_block();
+  // one lane adds the terms in order (the float rounding of the reference's loop); waves 1..3 stage the next 4 096
+  // terms into the other half of `buf` meanwhile, and the adding lane reads four terms per LDS access
   float ss = 0.f;
-  for (int base = 0; base < M; base += 4096)
+  const int wave = threadIdx.x >> 6;
+  for (int t = threadIdx.x; t < min(4096, M); t += blockDim.x)
+    buf[0][t] = S[t];
+  __syncthreads();
+  for (int base = 0, b = 0; base < M; base += 4096, b ^= 1)
   {
     const int cnt = min(4096, M - base);
-    for (int t = threadIdx.x; t < cnt; t += blockDim.x)
-      buf[t] = S[base + t];
-    __syncthreads();
-    if (threadIdx.x == 0)
-      for (int t = 0; t < cnt; t++)
-        ss += buf[t];
+    if (wave != 0)
+    {
+      const int nb = base + 4096;
+      if (nb < M)
+      {
+        const int cntn = min(4096, M - nb);
+        for (int t = threadIdx.x - 64; t < cntn; t += blockDim.x - 64)
+          buf[b ^ 1][t] = S[nb + t];
+      }
+    }
+    else if (threadIdx.x == 0)
+    {
+      const float4 *q = reinterpret_cast<const float4 *>(buf[b]);
+      const int n4 = cnt >> 2;
+#pragma unroll 8
+      for (int t = 0; t < n4; t++)
+      {
+        const float4 v = q[t];
+        ss += v.x;
+        ss += v.y;
+        ss += v.z;
+        ss += v.w;
+      }
+      for (int t = n4 << 2; t < cnt; t++)
+        ss += buf[b][t];
+    }
     __syncthreads();
   }
   if (threadIdx.x == 0)
