@@ -3,10 +3,12 @@
 
 One "step" = one pass of the hot path (projection -> CTF convolution -> FFT cross-correlation over the
 +-10 px displacement window -> log-sum-exp posterior) over this rank's orientation block against all
-particles, followed by the shard merge.  Workload at N GPUs (weak scaling, config 2 per GPU):
-  224^2 maps, 1 000 synthetic particles (replicated), 4 608 orientations PER GPU, 5 CTF envelopes,
-  441 displacements; rank r owns orientation block r of the global list (the reference's MPI sharding,
-  bioem.cpp:748-753); the merge of the per-particle posteriors is ONE all-gather over RCCL + a local fold.
+particles, followed by the shard merge.  Workload (weak scaling: 4 608 orientations PER GPU, rank r owns orientation
+block r of the global list = the reference's MPI sharding, bioem.cpp:748-753; the merge of the per-particle posteriors
+is ONE all-gather over RCCL + a local fold):
+  --config 2 (default below 8 GPUs)  BASELINE config 2 per GPU: 224^2, 1 000 particles, 5 CTF envelopes, 441 displacements
+  --config 3 (default at 8 GPUs)     BASELINE config 3: 224^2, 10 000 particles, 2 x 5 CTFs, 8 x 4 608 = 36 864 orientations
+Explicit --particles/--envelopes/... override either.
 
 Launch: `python bench.py --gpus N` starts N ranks itself when no launcher set WORLD_SIZE (the parent makes no GPU call
 and only forwards rank 0's line); under `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N` the
@@ -30,6 +32,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0               # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+FP32_VECTOR_PEAK_TFLOPS = 157.3     # same guide: 256 CUs x 4 SIMDs x 64 lanes x 2 flop (FMA) x 2.4 GHz
+POSTERIOR_FLOPS_PER_DISPLACEMENT = 230   # ~40 flop + 2 log + 1-2 exp in FP64 per displacement (~0.1 MFLOP / 441)
 VALU_PEAK_GINSTR = 1024 * 2.4 / 2   # 256 CUs x 4 SIMDs, one wave64 VALU instruction per 2 cycles at 2.4 GHz (same guide)
 
 
@@ -38,11 +42,14 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--particles", type=int, default=1000)
+    ap.add_argument("--config", choices=("auto", "2", "3"), default="auto",
+                    help="BASELINE.json configuration: 2 = 1 000 particles x 5 CTFs per GPU, 3 = 10 000 particles x 10 "
+                         "CTFs (the 8-GPU configuration); auto = 3 at --gpus 8, else 2")
+    ap.add_argument("--particles", type=int, default=None)
     ap.add_argument("--orientations", type=int, default=4608, help="orientations per GPU")
     ap.add_argument("--pixels", type=int, default=224)
     ap.add_argument("--envelopes", type=int, default=5, help="CTF_B_ENV grid points")
-    ap.add_argument("--defocus", type=int, default=1, help="CTF_DEFOCUS grid points (config 3: 2 x 5 envelopes = 10 CTFs)")
+    ap.add_argument("--defocus", type=int, default=None, help="CTF_DEFOCUS grid points (config 3: 2 x 5 envelopes = 10 CTFs)")
     ap.add_argument("--max-displacement", type=int, default=10, help="DISPLACE_CENTER half width (pixels)")
     ap.add_argument("--grid", type=int, default=1, help="DISPLACE_CENTER grid spacing")
     ap.add_argument("--write-angles", type=int, nargs="?", const=10, default=0, metavar="K",
@@ -51,30 +58,87 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-orientations", type=int, default=64, help="orientations of the CPU-baseline sample")
     ap.add_argument("--cpu-repeats", type=int, default=3)
-    return ap.parse_args()
+    args = ap.parse_args()
+    cfg = args.config if args.config != "auto" else ("3" if args.gpus == 8 else "2")
+    if args.particles is None:
+        args.particles = 10000 if cfg == "3" else 1000
+    if args.defocus is None:
+        args.defocus = 2 if cfg == "3" else 1
+    return args
 
 
-def self_launch(args):
-    """No launcher in the environment: start the N ranks as fresh child processes (this parent never touches the GPU;
-    nothing is exec'ed from a GPU-initialised process) and hand rank 0's output through."""
+def log_dir():
+    d = os.environ.get("BIOEM_BENCH_LOGDIR") or os.path.join(ROOT, "gpurun_out")
+    try:
+        os.makedirs(d, exist_ok=True)
+    except OSError:
+        d = os.getcwd()
+    return d
+
+
+def self_launch(n, child_argv, poll_s=0.2, out=None):
+    """No launcher in the environment: start the n ranks as fresh child processes (this parent never touches the GPU;
+    nothing is exec'ed from a GPU-initialised process), watch ALL of them, and hand rank 0's output through.  Every
+    rank's stderr goes to <log dir>/bench_rank<k>.err.  On the first non-zero exit the other ranks are terminated (they
+    would otherwise sit in the rendezvous or in the all-gather until the backend's timeout), the failed rank's
+    message is printed and its exit code returned."""
     import socket
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
-    procs = []
-    for r in range(args.gpus):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
-                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out, _ = procs[0].communicate()
-    rc = procs[0].returncode
-    for p in procs[1:]:
-        rc = p.wait() or rc
-    sys.stdout.write(out.decode())
-    sys.stdout.flush()
-    sys.exit(rc)
+    d = log_dir()
+    procs, errs = [], []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"),
+                   BIOEM_BENCH_LOGDIR=d, BIOEM_BENCH_SELF_LAUNCHED="1")
+        errs.append(open(os.path.join(d, "bench_rank%d.err" % r), "wb"))
+        procs.append(subprocess.Popen(child_argv, env=env, stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL,
+                                      stderr=errs[-1]))
+    import threading
+    chunks = []
+    reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    failed = None
+    while failed is None:
+        codes = [p.poll() for p in procs]
+        for r, c in enumerate(codes):
+            if c not in (None, 0):
+                failed = (r, c)
+                break
+        if failed is None and all(c == 0 for c in codes):
+            break
+        time.sleep(poll_s)
+    if failed is not None:
+        for p in procs:
+            if p.poll() is None:
+                p.terminate()
+        deadline = time.time() + 5.0
+        for p in procs:
+            try:
+                p.wait(timeout=max(0.1, deadline - time.time()))
+            except subprocess.TimeoutExpired:
+                p.kill()            # the exact child this parent started, by handle
+                p.wait()
+    reader.join(timeout=5.0)
+    for f in errs:
+        f.close()
+    out = out or sys.stdout
+    out.write(b"".join(c for c in chunks if c).decode(errors="replace"))
+    out.flush()
+    if failed is not None:
+        r, c = failed
+        path = os.path.join(d, "bench_rank%d.err" % r)
+        try:
+            with open(path, "rb") as f:
+                tail = f.read()[-4000:].decode(errors="replace")
+        except OSError:
+            tail = ""
+        sys.stderr.write("bench.py: rank %d of %d exited with code %d; the other ranks were terminated.  Its stderr "
+                         "(%s):\n%s\n" % (r, n, c, path, tail))
+        return c
+    return 0
 
 
 def cpu_model():
@@ -101,7 +165,16 @@ def cpu_baseline(W, n_orient, n_threads, repeats):
     pd = orc.ParamDevice()
     for f, _ in orc.ParamDevice._fields_:
         setattr(pd, f, getattr(W.pd, f))
-    refFFT, sumRef, sumsqRef = W.engine.debug_particles()
+    # the oracle's OWN particle inputs (r2c + sequential float sums of the real-space stack, map.cpp:557-630,
+    # bioem.cpp:2087-2107): the device particle transform must not sit on both sides of the parity object
+    refFFT = np.stack([orc.fft2_r2c(m) for m in W.maps])
+    sums = [orc.map_sums(m) for m in W.maps]
+    sumRef = np.array([a for a, _ in sums], dtype=np.float32)
+    sumsqRef = np.array([b for _, b in sums], dtype=np.float32)
+    dspec, dsum, dsumsq = W.engine.debug_particles()
+    particle_check = {"sums_bitwise_equal": bool(np.array_equal(dsum, sumRef) and np.array_equal(dsumsq, sumsqRef)),
+                      "spectra_max_rel_diff": float(np.abs(dspec - refFFT).max() / np.abs(refFFT).max())}
+    del dspec
     pts = np.zeros(len(W.points), dtype=orc.POINT_DTYPE)
     for k in ("pos", "radius", "density"):
         pts[k] = W.points[k]
@@ -115,13 +188,16 @@ def cpu_baseline(W, n_orient, n_threads, repeats):
                   sumsqRef.ctypes.data, 0, n_orient, pmap.ctypes.data, None)
         times.append(time.time() - t0)
     dt = sorted(times)[len(times) // 2]
-    return n_orient * W.nCTF * nP / dt, times, pmap, orc.logp_constant(pd)
+    return n_orient * W.nCTF * nP / dt, times, pmap, orc.logp_constant(pd), particle_check
 
 
 def main():
     args = parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        self_launch(args)
+        sys.exit(self_launch(args.gpus, [sys.executable, os.path.abspath(__file__)] + sys.argv[1:]))
+    t_start = time.perf_counter()
+    if os.environ.get("BIOEM_BENCH_INJECT_FAILURE") == os.environ.get("RANK", "0"):
+        raise RuntimeError("injected failure on rank %s (BIOEM_BENCH_INJECT_FAILURE)" % os.environ.get("RANK", "0"))
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -143,11 +219,14 @@ def main():
     torch.cuda.set_device(gpu_index)
     dev = torch.device("cuda", gpu_index) if backend == "nccl" else torch.device("cpu")
     if world > 1:
+        import datetime
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        # a rank that never arrives must not hold the others for the backend's default half hour
+        rdv = datetime.timedelta(seconds=float(os.environ.get("BIOEM_BENCH_RENDEZVOUS_S", "120")))
         if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev, timeout=rdv)
         else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
+            dist.init_process_group(backend, rank=rank, world_size=world, timeout=rdv)
 
     from bioem_amd.dist_merge import merge_prob_maps
     from bioem_amd.engine import new_prob_block
@@ -176,7 +255,10 @@ def main():
         cands = E.topk_angles(K, numconst) if K else None      # K x nMaps x 32 B instead of the table
         if world > 1:
             # the path's single exchange step (reference: MPI merge, bioem.cpp:909-1044): one all-gather + fold
-            return merge_prob_maps(pmap, dev, cands=cands)
+            tm = time.perf_counter()
+            merged = merge_prob_maps(pmap, dev, cands=cands)
+            merge_s[0] += time.perf_counter() - tm
+            return merged
         return (pmap, cands) if K else pmap
 
     def sync():
@@ -184,10 +266,25 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    merge_s = [0.0]
+    comm_setup_s = 0.0
+    if world > 1:
+        # communicator creation (RCCL builds its rings on the first collective) stays outside the timed region even
+        # with --warmup 0: one tiny all-gather + barrier here
+        tc = time.perf_counter()
+        probe = torch.zeros(8, dtype=torch.uint8, device=dev)
+        sink = torch.empty(8 * world, dtype=torch.uint8, device=dev)
+        dist.all_gather_into_tensor(sink, probe)
+        dist.barrier()
+        if backend == "nccl":
+            torch.cuda.synchronize()
+        comm_setup_s = time.perf_counter() - tc
     for _ in range(args.warmup):
         one_step()
     sync()
     E.reset_kernel_stats()
+    merge_s[0] = 0.0
+    setup_s = time.perf_counter() - t_start
     t0 = time.perf_counter()
     for _ in range(args.steps):
         last = one_step()
@@ -209,7 +306,8 @@ def main():
         pass
     shape = (W.N, W.nP, W.nOrient, W.nCTF, args.max_displacement, args.grid)
     workload_name = {(224, 1000, 4608, 5, 10, 1): "BASELINE config 2 per GPU",
-                     (224, 10000, 4608, 10, 10, 1): "BASELINE config 3, one GPU's share of 8"}.get(shape, "custom")
+                     (224, 10000, 4608, 10, 10, 1): "BASELINE config 3 (10 000 particles, 36 864 orientations, 10 CTFs)"
+                     if world == 8 else "BASELINE config 3, one GPU's share of 8"}.get(shape, "custom")
     total_comparisons = world * W.comparisons_per_pass * args.steps
     value = total_comparisons / dt
     b_alg = 8 * W.N * (W.N // 2 + 1)  # bytes: one read of the particle half-spectrum per comparison
@@ -225,6 +323,12 @@ def main():
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": 1e3 * dt / args.steps,
+        # inside ms_per_step: this rank's share of it spent in the shard merge (D2H of the 40-byte entries, ONE
+        # all-gather, host fold); outside: everything before the timed region (imports, particle rendering, uploads,
+        # communicator creation, warm-up)
+        "merge_ms": (1e3 * merge_s[0] / args.steps) if world > 1 else 0.0,
+        "setup_s": setup_s,
+        "comm_setup_s": comm_setup_s,
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
@@ -244,6 +348,20 @@ def main():
           "traffic": None, "kernel": sig, "launches": int(launches), "avg_launch_ms": avg_ms,
           "comparisons_per_launch": cpl,
           "peak_definition": "1024 SIMDs x 2.4 GHz / 2 cycles per wave64 VALU instruction (MI355X_MICROARCH.md)"}
+    # work-based bound (secondary): what the REFERENCE algorithm spends per comparison -- spectrum product
+    # 6 M + full unpruned 2-D c2r 2.5 N^2 log2(N^2) + posterior per displacement -- at the measured rate, against the
+    # FP32 vector peak.  Independent of how many instructions this kernel issues for that work (the pruned transforms
+    # need ~0.85 M lane-operations for it): a kernel that issues twice the instructions does NOT score the same here.
+    import math
+    M = W.N * (W.N // 2 + 1)
+    alg_flops = 6.0 * M + 2.5 * W.N * W.N * math.log2(W.N * W.N) + int(W.pd.NtotDisp) * POSTERIOR_FLOPS_PER_DISPLACEMENT
+    rl["alg_flops_per_comparison"] = alg_flops
+    rl["alg_flops_definition"] = ("6 M + 2.5 N^2 log2(N^2) + NtotDisp x %d (SURVEY.md 8d: the reference's product, full "
+                                  "c2r and posterior)" % POSTERIOR_FLOPS_PER_DISPLACEMENT)
+    rl["alg_TFLOPs_whole_job"] = value * alg_flops / 1e12 / world          # per GPU
+    rl["alg_TFLOPs_kernel"] = (ncomp * alg_flops / 1e12) / (kms / 1e3) if kms > 0 else None
+    rl["fp32_vector_peak_TFLOPs"] = FP32_VECTOR_PEAK_TFLOPS
+    rl["frac_of_fp32_vector_peak"] = (rl["alg_TFLOPs_kernel"] / FP32_VECTOR_PEAK_TFLOPS) if rl["alg_TFLOPs_kernel"] else None
     hbm = {"peak_GBps": HBM_PEAK_GBS, "alg_bytes_per_comparison": b_alg,
            "alg_GBps": (ncomp * b_alg / 1e9) / (kms / 1e3) if kms > 0 else None,
            "alg_note": "north-star model (one particle half-spectrum per comparison); L1/L2 reuse makes it exceed the "
@@ -257,6 +375,12 @@ def main():
                 abs(cpl - pmc["comparisons_per_launch"]) < 1 and pmc["config"]["pixels"] == W.N and
                 pmc["config"]["particles"] == W.nP and pmc["config"]["ctf"] == W.nCTF and
                 pmc["config"]["displacements"] == int(W.pd.NtotDisp))
+        from bioem_amd.buildinfo import source_blobs
+        stale = [k for k, v in source_blobs().items() if pmc.get("source_blobs", {}).get(k) != v]
+        if same and stale:
+            same = False
+            rl["counters_refused"] = ("profiles/pmc_current.json was measured on other device sources (git blob hash "
+                                      "differs: %s); re-run scripts/profile_round.sh" % ", ".join(stale))
         if same and avg_ms:
             d = pmc["derived"]
             ipc = d["valu_wave_instr_per_comparison"]
@@ -265,7 +389,9 @@ def main():
             rl["frac"] = rl["achieved"] / VALU_PEAK_GINSTR
             rl["clock_mhz_under_pmc"] = d.get("clock_mhz_under_pmc")
             rl["frac_at_sustained_clock"] = d.get("valu_issue_frac_at_sustained_clock")
-            rl["counters_source"] = "profiles/%s_pmc_summary.json (same kernel instantiation and launch shape)" % pmc["tag"]
+            rl["utilisation"] = "frac = VALU issue utilisation: counter-measured wave-instructions of this build at the live launch time"
+            rl["counters_source"] = ("profiles/%s_pmc_summary.json (same kernel instantiation, launch shape and git blob "
+                                     "hashes of bioem_amd/csrc/*)" % pmc["tag"])
             rl["traffic"] = d.get("traffic_bytes_per_launch")
             hbm["counter_bytes_per_launch"] = d.get("traffic_bytes_per_launch")
             if d.get("traffic_bytes_per_launch"):
@@ -273,7 +399,7 @@ def main():
                 hbm["frac_of_peak"] = hbm["counter_GBps"] / HBM_PEAK_GBS
             hbm["l2_hit_rate"] = d.get("l2_hit_rate")
         else:
-            rl["counters_source"] = "none: profiles/pmc_current.json is for another kernel or launch shape"
+            rl["counters_source"] = "none: profiles/pmc_current.json is for another kernel, launch shape or source tree"
     except (OSError, KeyError, ValueError, TypeError):
         rl["counters_source"] = "none: profiles/pmc_current.json missing"
     out["roofline"] = rl
@@ -294,7 +420,7 @@ def main():
         # where neither tells the share (all 256 host cores visible, quota unlimited) BIOEM_CPU_THREADS sets it
         nthreads = orc.usable_cpus(cap=int(os.environ.get("BIOEM_CPU_THREADS", 1 << 20)))
         nco = min(args.cpu_orientations, W.nOrient)
-        v, times, want, const = cpu_baseline(W, nco, nthreads, max(1, args.cpu_repeats))
+        v, times, want, const, particle_check = cpu_baseline(W, nco, nthreads, max(1, args.cpu_repeats))
         import ctypes.util
         out["cpu_baseline"] = {"value": v, "unit": "comparisons/s", "cores": nthreads, "kind": "port",
                                "cpu_model": cpu_model(), "host_cores_total": os.cpu_count(),
@@ -312,7 +438,9 @@ def main():
         lb = np.log(want["Total"]) + want["Constoadd"] + const
         same = ((got["orient"] == want["orient"]) & (got["conv"] == want["conv"]) &
                 (got["cent_x"] == want["cent_x"]) & (got["cent_y"] == want["cent_y"]))
-        out["parity"] = {"against": "CPU oracle on the cpu_baseline sample", "particles": int(nMaps),
+        out["parity"] = {"against": "CPU oracle on the cpu_baseline sample, particle spectra and sums computed by the "
+                                    "oracle from the real-space stack", "particles": int(nMaps),
+                         "device_particle_transform_vs_oracle": particle_check,
                          "max_abs_dlogp": float(np.abs(la - lb).max()),
                          "max_rel_dlogp": float((np.abs(la - lb) / np.abs(lb)).max()),
                          "argmax_mismatches": int((~same).sum()), "tolerance_rel": 1e-4}
@@ -323,4 +451,18 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    try:
+        main()
+    except SystemExit:
+        raise
+    except BaseException:
+        # under a launcher the ranks' stderr is interleaved (or lost): every rank keeps its own traceback in a file
+        import traceback
+        if not os.environ.get("BIOEM_BENCH_SELF_LAUNCHED"):        # (self-launched ranks: stderr IS that file)
+            try:
+                with open(os.path.join(log_dir(), "bench_rank%s.err" % os.environ.get("RANK", "0")), "a") as f:
+                    traceback.print_exc(file=f)
+            except OSError:
+                pass
+        traceback.print_exc()
+        sys.exit(3)

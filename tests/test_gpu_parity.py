@@ -186,9 +186,12 @@ def test_device_projection_and_convolution(name):
     E.close()
 
 
-def test_device_particle_precompute():
-    """sum_RefMap / sumsquare_RefMap (same float summation order: bitwise) and the particle r2c on the device."""
-    case, S = setup_for("g2_n128")
+@pytest.mark.parametrize("name", ["g2_n128", "g7_n224", "g19_n200", "g20_n256", "g9_n35_odd", "g18_n50", "g1_n48"])
+def test_device_particle_precompute(name):
+    """sum_RefMap / sumsquare_RefMap (same float summation order: bitwise) and the particle r2c on the device against
+    the oracle's precalculate (map.cpp:557-630, bioem.cpp:2087-2107) at every BASELINE image size (128, 224, 256),
+    the mixed-radix 200, an odd size and two small even ones; then the whole path from those device spectra."""
+    case, S = setup_for(name)
     E = make_engine(S, 1, real_space_particles=True)
     spec, s, s2 = E.debug_particles()
     assert np.array_equal(s, S.sumRef) and np.array_equal(s2, S.sumsqRef)
@@ -197,6 +200,18 @@ def test_device_particle_precompute():
     want, _ = S.run(1)
     assert_same_posterior(S, pmap, want)
     E.close()
+
+
+def test_device_particle_precompute_odd_size_above_35_and_full_stack():
+    """The same chain on synthetic stacks the goldens do not hold: odd sizes above 35 (75, 127, 225) and all 1 000
+    particles of the BASELINE config-2 stack (224^2) -- every particle, not a slice."""
+    from bioem_amd.synthetic import Workload
+    for N, nP in ((75, 5), (127, 4), (225, 3), (224, 1000)):
+        W = Workload(N=N, nP=nP, nOrient=4, nEnv=1, npts=200)
+        try:
+            assert_device_particles_match(W.engine, W.maps, list(range(nP)))
+        finally:
+            W.engine.close()
 
 
 def test_write_prob_angles():
@@ -430,7 +445,7 @@ def test_invalid_configuration_is_rejected():
     E.close()
 
 
-CLI_CASES = ["g10_n64", "g9_n35_odd", "g4_n32_angles", "g5_n32_psf", "g11_n32_eulerlist", "g12_n32_misc",
+CLI_CASES = ["g10_n64", "g1_n48", "g7_n224", "g19_n200", "g9_n35_odd", "g4_n32_angles", "g5_n32_psf", "g11_n32_eulerlist", "g12_n32_misc",
              "g13_n32_psf_writectf", "g14_n32_mrc", "g15_n32_mrc_nonorm", "g16_n40", "g17_n36", "g18_n50",
              "g20_n256", "g21_n64_wide20", "g22_n128_wide40", "g23_n128_tutorial", "g24_n32_pdb", "g25_n32_modelmrc",
              "g26_n32_multimrc"]
@@ -540,6 +555,41 @@ def test_cli_accepts_the_reference_performance_knobs(tmp_path):
         assert (g["angles"], g["ctf"], g["cx"], g["cy"]) == (m["angles"], m["ctf"], m["cx"], m["cy"])
 
 
+REF_HIP = os.path.join(ROOT, "oracle", "_ref", "bioEM_ref_hip")
+
+
+@pytest.mark.skipif(not os.path.exists(REF_HIP), reason="oracle/_ref/bioEM_ref_hip is not on this box (it travels only "
+                    "with scripts/gpurun_with_reference.sh)")
+@pytest.mark.parametrize("name", ["g10_n64", "g4_n32_angles", "g2_n128", "g7_n224", "g22_n128_wide40"])
+def test_reference_binary_drives_this_build(name, tmp_path):
+    """The compiled drop-in against THIS build of libbioem_hip.so (the committed plugin outputs record one past run):
+    the unmodified reference sources + oracle/ref_plugin (`make -C oracle ref_hip`), GPU=1, the reference's own run()
+    loop calling the engine through the compareRefMaps virtual (bioem.cpp:853) -- outputs against the reference CPU
+    path's committed files."""
+    case, S = setup_for(name)
+    args = write_case_inputs(case, tmp_path)
+    for algo in case["algos"]:
+        env = dict(os.environ, OMP_NUM_THREADS="1", BIOEM_ALGO=str(algo), BIOEM_DEBUG_OUTPUT="0", GPU="1")
+        if algo == 2:
+            env["BIOEM_PROJ_CONV_AT_ONCE"] = "3"
+        env.update(case["env"])
+        r = subprocess.run([REF_HIP, "--Inputfile", os.path.join(case["dir"], "param.txt"), "--OutputFile", "out.txt"]
+                           + args, cwd=str(tmp_path), env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                           text=True, timeout=600)
+        assert r.returncode == 0, r.stdout[-2000:]
+        gold = iof.parse_output_probabilities(golden_output(case, algo))
+        mine = iof.parse_output_probabilities(open(tmp_path / "out.txt").read())
+        assert len(gold) == len(mine) > 0
+        for g, m in zip(gold, mine):
+            assert abs(g["logp"] - m["logp"]) <= max(ABS_TOL, REL_TOL * abs(g["logp"]))
+            assert (g["angles"], g["ctf"], g["cx"], g["cy"]) == (m["angles"], m["ctf"], m["cx"], m["cy"])
+        if S.pd.writeAngles:
+            ga = iof.parse_ang_prob(os.path.join(case["dir"], "ANG_PROB_algo%d" % algo))
+            ma = iof.parse_ang_prob(str(tmp_path / "ANG_PROB"))
+            for m_ in ga:
+                assert [g["angles"] for g in ga[m_]] == [m["angles"] for m in ma[m_]]
+
+
 def test_cli_error_behaviour(tmp_path):
     """Errors print 'Error - ...' and exit 1 like the reference's myError (defs.h:18-26)."""
     exe = os.path.join(ROOT, "bioem_amd", "bin", "bioEM")
@@ -589,12 +639,32 @@ def test_full_size_sharding_invariance_and_planted_truth(full_workload):
     assert np.mean(full["orient"] == truth) > 0.9
 
 
-def oracle_on_workload(W, sel, nO, algo=1, angles=False, engine=None):
-    """orientations [0, nO) x all CTFs x the particles `sel` of a synthetic workload through the CPU oracle
-    (from the engine's own particle spectra, so that the comparison path alone is under test).  angles=True also
-    returns the oracle's angle table [nOrient][len(sel)]."""
+def oracle_particle_inputs(maps, sel):
+    """What PreCalculateMapsFFT / precalculate hand to the compare path (map.cpp:557-630, bioem.cpp:2087-2107) for the
+    particles `sel`, computed by the ORACLE from the real-space maps: r2c spectra and the two sequential float sums."""
+    rsel = np.stack([orc.fft2_r2c(maps[p]) for p in sel])
+    sums = [orc.map_sums(maps[p]) for p in sel]
+    return (np.ascontiguousarray(rsel), np.array([s for s, _ in sums], dtype=np.float32),
+            np.array([s2 for _, s2 in sums], dtype=np.float32))
+
+
+def assert_device_particles_match(E, maps, sel):
+    """The device particle chain of bioem_hip_upload_particle_maps (k_map_sums, k_dft_rows/cols, k_reorder) against
+    the oracle's precalculate on the same maps: sums bitwise (same summation order), spectra to float rounding."""
+    spec, s, s2 = E.debug_particles()
+    rsel, ssel, s2sel = oracle_particle_inputs(maps, sel)
+    assert np.array_equal(s[sel], ssel) and np.array_equal(s2[sel], s2sel)
+    assert np.abs(spec[sel] - rsel).max() <= 2e-6 * np.abs(rsel).max()
+    return rsel, ssel, s2sel
+
+
+def oracle_on_workload(W, sel, nO, algo=1, angles=False, engine=None, maps=None):
+    """orientations [0, nO) x all CTFs x the particles `sel` of a synthetic workload through the CPU oracle.  The
+    oracle computes its own particle spectra and sums from the real-space maps (`maps`, default W.maps), so the device
+    particle transform is NOT on both sides; the engine's copies are asserted against them on the way.  angles=True
+    also returns the oracle's angle table [nOrient][len(sel)]."""
     import ctypes as C
-    refFFT, sumRef, sumsqRef = (engine or W.engine).debug_particles()
+    rsel, ssel, s2sel = assert_device_particles_match(engine or W.engine, W.maps if maps is None else maps, sel)
     nsel = len(sel)
     pd = orc.ParamDevice()
     for f, _ in orc.ParamDevice._fields_:
@@ -609,8 +679,6 @@ def oracle_on_workload(W, sel, nO, algo=1, angles=False, engine=None):
                     wang.ctypes.data if angles else None)
     if not angles:
         pd.writeAngles = 0
-    rsel = np.ascontiguousarray(refFFT[sel])
-    ssel, s2sel = np.ascontiguousarray(sumRef[sel]), np.ascontiguousarray(sumsqRef[sel])
     L.orc_run(C.byref(pd), algo, pts.ctypes.data, len(pts), W.NormDen, W.angles.ctypes.data, W.nOrient, 1, W.px, 0,
               0, W.nCTF, W.refCTF.ctypes.data, W.ctfParam.ctypes.data, nsel, rsel.ctypes.data, ssel.ctypes.data,
               s2sel.ctypes.data, 0, nO, want.ctypes.data, wang.ctypes.data if angles else None)
@@ -741,7 +809,7 @@ def test_config5_shape_two_shards_device_top_k(tmp_path):
     Es.upload_orientations(W.angles, True)
     _, got = run_shard(Es, 0, 12)
     cs = Es.topk_angles(K, numconst)
-    want, const, wang = oracle_on_workload(W, sel, 12, angles=True, engine=Es)
+    want, const, wang = oracle_on_workload(W, sel, 12, angles=True, engine=Es, maps=maps)
     assert_workload_matches(got, want, const, sel)
     import heapq
     for i, p in enumerate(sel):
@@ -990,7 +1058,7 @@ def test_config4_shape_against_direct_real_space_correlation():
     assert raw.tobytes() == raw2.tobytes()
     truth = (7919 * np.arange(W.nP)) % W.nOrient
     assert np.mean(full["orient"] == truth) > 0.9
-    _, sumRef, sumsqRef = W.engine.debug_particles()
+    _, sumRef, sumsqRef = oracle_particle_inputs(W.maps, list(range(W.nP)))      # the oracle's own sums
     pd = orc.ParamDevice()
     for f, _ in orc.ParamDevice._fields_:
         setattr(pd, f, getattr(W.pd, f))

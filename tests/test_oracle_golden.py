@@ -15,7 +15,7 @@ import pytest
 
 import io_formats as iof
 import oracle as orc
-from golden_util import CASES, golden_output, load_case, oracle_setup
+from golden_util import CASES, GOLDEN, golden_output, load_case, oracle_setup
 
 # |log P| differences come only from float rounding inside the FFT backend (hipFFT float vs the
 # oracle's double DFT); observed <= 2.2e-3 at 224^2 (3e-8 relative).  north_star tolerance: 1e-4 relative.
@@ -156,3 +156,26 @@ def test_reference_driving_the_hip_plugin_equals_reference_cpu(name):
                 assert len(ga[m]) == len(pa[m])
                 for g, p in zip(ga[m], pa[m]):
                     assert g["angles"] == p["angles"] and abs(g["logp"] - p["logp"]) <= ABS_TOL
+
+
+def test_c2r_of_a_non_hermitian_half_spectrum_three_implementations():
+    """The one convention of the reference's FFT dependency that the goldens pin only through hipFFTW (FFTW is absent
+    from the image; the reference holds no fixtures): the unnormalised 2-D c2r (fftwf_plan_dft_c2r_2d,
+    bioem.cpp:1458 / param.cpp:1521) of a half-spectrum that is NOT Hermitian in columns 0 and N/2 -- what the CTF row
+    quirk (param.cpp:1560-1568) hands to it.  FFTW's documented rdft2 behaviour: complex transform along the first
+    axis, then a c2r along the last that ignores the imaginary parts of its DC and Nyquist inputs.  Three independent
+    implementations must agree on seeded random spectra: the oracle's double-precision DFT, numpy's pocketfft irfft2,
+    and hipFFTW's output committed in tests/golden/c2r_nonhermitian.npz (oracle/fft_probe/make_fixture.py, run on
+    the GPU box).  This documents the convention; it is not a pin against FFTW itself."""
+    d = np.load(os.path.join(GOLDEN, "c2r_nonhermitian.npz"))
+    for N in [int(n) for n in d["sizes"]]:
+        spec = d["in_%d" % N]
+        assert np.abs(spec[:, 0, 1]).max() > 0.1 and np.abs(spec[0, :, 1]).max() > 0.1         # really not Hermitian
+        mine = orc.fft2_c2r(spec).astype(np.float64)
+        z = spec[..., 0].astype(np.float64) + 1j * spec[..., 1].astype(np.float64)
+        pocket = np.fft.irfft2(z, s=(N, N)) * (N * N)
+        hipfftw = d["hipfftw_%d" % N].astype(np.float64)
+        scale = np.abs(pocket).max()
+        assert np.abs(mine - pocket).max() <= 2e-6 * scale
+        assert np.abs(hipfftw - pocket).max() <= 2e-5 * scale
+        assert np.abs(hipfftw - mine).max() <= 2e-5 * scale
