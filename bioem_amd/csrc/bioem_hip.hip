@@ -109,6 +109,7 @@ struct bioem_hip_ctx
   // k_compare_wide2 (compare_wide2.hpp): wide window in ONE launch per batch -- column transforms shared by the four
   // waves of a comparison, row FFT
   bool wide2 = false;
+  bool fastm = false; // 23..31-row windows: k_compare_fastm (window pass on the matrix cores)
   int w2NRW = 0, w2NBLK = 0, w2TS = 0, w2Rows2 = 0, nyqWD = 0, w2Halves = 1, w2NW = 4;
   float2 *dTwk2 = nullptr; // [N1][nd] recombination twiddles exp(2 pi i dx k1 / N), rows in sorted order
   float2 *dConvShift = nullptr;
@@ -209,6 +210,7 @@ struct bioem_hip_ctx
 #include "compare_fast.hpp"
 #include "compare_wide.hpp"
 #include "compare_wide2.hpp"
+#include "compare_fastm.hpp"
 #include "compare_generic.hpp"
 #include "compare_rows.hpp"
 #include "fold_kernels.hpp"
@@ -287,6 +289,7 @@ BatchBuf batch_buf(bioem_hip_ctx *h, int which)
 
 // the fast-kernel instantiation for a window half width (10 or 15) and register-FFT length (32, 16, 8)
 typedef void (*fast_kernel_t)(const CompareArgs);
+#ifndef BIOEM_SLIM
 template <int WD, int GS>
 fast_kernel_t fast_kernel_r(int R, bool nyq)
 {
@@ -328,8 +331,12 @@ fast_kernel_t wide_kernel_r(int gs, int wpc)
     return wpc == 2 ? k_compare_wide<R, 1, 2, NYQ> : k_compare_wide<R, 1, 4, NYQ>;
   return wpc == 2 ? k_compare_wide<R, 2, 2, NYQ> : k_compare_wide<R, 2, 4, NYQ>;
 }
+#endif // BIOEM_SLIM
 fast_kernel_t wide_kernel(int R, int gs, int wpc, bool nyq)
 {
+#ifdef BIOEM_SLIM
+  return nullptr;
+#else
   if (nyq) // N/2 a multiple of 64 implies R = 32
     return wide_kernel_r<32, true>(gs, wpc);
   switch (R)
@@ -347,6 +354,7 @@ fast_kernel_t wide_kernel(int R, int gs, int wpc, bool nyq)
   case 10: return wpc == 2 ? k_compare_wide<10, 1, 2, false> : k_compare_wide<10, 1, 4, false>;
   default: return wpc == 2 ? k_compare_wide<6, 1, 2, false> : k_compare_wide<6, 1, 4, false>;
   }
+#endif
 }
 size_t wide_lds_bytes(int N, int H, int wpc, bool nyq)
 { // tables + per comparison one T block [21][66] per 64-column block
@@ -354,6 +362,7 @@ size_t wide_lds_bytes(int N, int H, int wpc, bool nyq)
   return (size_t) ((N + 2) & ~1) * 8 + 256 + 1024 + (size_t) (4 / wpc) * nblk * 21 * 66 * 8;
 }
 
+#ifndef BIOEM_SLIM
 // k_compare_wide2 instantiations: every register-FFT length; (rows per wave, column blocks) = (32, 1) or (21, 2)
 template <int R>
 fast_kernel_t wide2_kernel_r(int nblk, bool nyq, int halves)
@@ -470,8 +479,16 @@ fast_kernel_t wide2_kernel_w8_4(int R, bool nyq, int halves)
     return halves == 2 ? k_compare_wide2<32, 11, 4, false, 2, 8> : k_compare_wide2<32, 11, 4, false, 1, 8>;
   return halves == 2 ? k_compare_wide2<16, 11, 4, false, 2, 8> : k_compare_wide2<16, 11, 4, false, 1, 8>;
 }
+#endif // BIOEM_SLIM
 fast_kernel_t wide2_pick(int R, int nrw, int nblk, bool nyq, int halves, int nw = 4)
 {
+#ifdef BIOEM_SLIM
+#ifdef BIOEM_SLIM_W2
+  return k_compare_wide2<BIOEM_SLIM_W2>;
+#else
+  return nullptr;
+#endif
+#else
   if (nw == 8 && nblk == 4)
     return wide2_kernel_w8_4(R, nyq, halves);
   if (nw == 8)
@@ -481,6 +498,7 @@ fast_kernel_t wide2_pick(int R, int nrw, int nblk, bool nyq, int halves, int nw 
   if (nblk == 2 && nrw <= 13)
     return wide2_kernel_small(R, nrw, nyq);
   return wide2_kernel(R, nblk, nyq, halves, nrw);
+#endif
 }
 size_t wide2_lds_bytes(int N, int R, int rows2, int ts, int nw = 4)
 { // tables (twiddles, visiting ranks, log table, wave results, posterior constants) + max(one FFT-output slot per wave, T block)
@@ -488,6 +506,55 @@ size_t wide2_lds_bytes(int N, int R, int rows2, int ts, int nw = 4)
   return (size_t) ((N + 2) & ~1) * 8 + 512 + 1024 + 256 + std::max(slots, tblock);
 }
 
+// k_compare_fastm instantiations: 27- and 31-row windows, register-FFT lengths up to 16 (three waves per SIMD), row strides
+// 1..4 for the power-of-two lengths, Nyquist split with 16 points
+size_t fastm_lds_bytes(int N)
+{ // cos / sin planes of the twiddle table (padded), window ranks, log table, per wave two 32 x 33 float planes and the
+  // resting place of the 16 tile accumulators
+  return (size_t) 2 * fastm_table_floats(N) * 4 + 128 + 1024 + (size_t) 4 * 2 * 32 * 33 * 4 + (size_t) 4 * 16 * 64 * 4;
+}
+#ifndef BIOEM_SLIM
+template <int WD, int GS>
+fast_kernel_t fastm_kernel_r(int R, bool nyq)
+{
+  if (nyq)
+    return k_compare_fastm<WD, 16, true, GS>;
+  if constexpr (GS == 1)
+  {
+    switch (R)
+    {
+    case 6: return k_compare_fastm<WD, 6, false, 1>;
+    case 10: return k_compare_fastm<WD, 10, false, 1>;
+    case 12: return k_compare_fastm<WD, 12, false, 1>;
+    default: break;
+    }
+  }
+  return R == 16 ? k_compare_fastm<WD, 16, false, GS>
+         : R == 8 ? k_compare_fastm<WD, 8, false, GS>
+         : R == 4 ? k_compare_fastm<WD, 4, false, GS>
+                  : k_compare_fastm<WD, 2, false, GS>;
+}
+template <int WD>
+fast_kernel_t fastm_kernel_g(int R, bool nyq, int gs)
+{
+  return gs == 1 ? fastm_kernel_r<WD, 1>(R, nyq) : gs == 2 ? fastm_kernel_r<WD, 2>(R, nyq)
+         : gs == 3 ? fastm_kernel_r<WD, 3>(R, nyq) : fastm_kernel_r<WD, 4>(R, nyq);
+}
+#endif // BIOEM_SLIM
+fast_kernel_t fastm_kernel(int winD, int R, bool nyq, int gs)
+{
+#ifdef BIOEM_SLIM
+#ifdef BIOEM_SLIM_FASTM
+  return k_compare_fastm<BIOEM_SLIM_FASTM>;
+#else
+  return nullptr;
+#endif
+#else
+  return winD == 13 ? fastm_kernel_g<13>(R, nyq, gs) : fastm_kernel_g<15>(R, nyq, gs);
+#endif
+}
+
+#ifndef BIOEM_SLIM
 template <int WD>
 fast_kernel_t rows_kernel_g(int gs)
 {
@@ -500,22 +567,35 @@ fast_kernel_t oddfft_kernel_r(int R)
   return R == 25 ? k_compare_oddfft<WD, 25> : R == 15 ? k_compare_oddfft<WD, 15> : R == 9 ? k_compare_oddfft<WD, 9>
          : R == 5 ? k_compare_oddfft<WD, 5> : k_compare_oddfft<WD, 3>;
 }
+#endif // BIOEM_SLIM
 // odd N: register FFT of odd length R over the reference layout if R > 0 (unit row stride), else direct column sums
 fast_kernel_t rows_kernel(int winD, int gs, int oddR = 0)
 {
+#ifdef BIOEM_SLIM
+  return nullptr;
+#else
   if (oddR)
     return winD == 5 ? oddfft_kernel_r<5>(oddR) : winD == 10 ? oddfft_kernel_r<10>(oddR)
            : winD == 13 ? oddfft_kernel_r<13>(oddR) : oddfft_kernel_r<15>(oddR);
   return winD == 5 ? rows_kernel_g<5>(gs) : winD == 10 ? rows_kernel_g<10>(gs) : winD == 13 ? rows_kernel_g<13>(gs)
                                                                                              : rows_kernel_g<15>(gs);
+#endif
 }
 
 fast_kernel_t fast_kernel(int winD, int R, bool nyq, int gs)
 {
-  return winD == 5    ? fast_kernel_g<5>(R, nyq, gs)
-         : winD == 10 ? fast_kernel_g<10>(R, nyq, gs)
-         : winD == 13 ? fast_kernel_g<13>(R, nyq, gs)
-                      : fast_kernel_g<15>(R, nyq, gs);
+#ifdef BIOEM_SLIM
+  // experiment builds (scripts/slim_build.sh, never shipped): only the instantiations named on the command line are
+  // compiled -- seconds instead of minutes; a shape that selects anything else gets a null kernel and fails the launch
+#ifdef BIOEM_SLIM_FAST
+  return k_compare_fast<BIOEM_SLIM_FAST>;
+#else
+  return nullptr;
+#endif
+#else
+  // (27- and 31-row windows run k_compare_fastm)
+  return winD == 5 ? fast_kernel_g<5>(R, nyq, gs) : fast_kernel_g<10>(R, nyq, gs);
+#endif
 }
 
 // ids == nullptr: row oc of the launch is (orient0 + oc / convPerOrient, conv0 + oc % convPerOrient) (native path);
@@ -588,7 +668,8 @@ int launch_compare_fold(bioem_hip_ctx *h, const BatchBuf &bb, int nOC, int orien
   else if (h->fast || h->rowsK)
   {
     const int NW = 2 * h->winD + 1;
-    const size_t lds = fast_lds_bytes(h->N, NW, 4, h->fast ? fast_half_t(h->winD, 2 * h->fast) : false);
+    const size_t lds = h->fastm ? fastm_lds_bytes(h->N)
+                                : fast_lds_bytes(h->N, NW, 4, h->fast ? fast_half_t(h->winD, 2 * h->fast) : false);
     auto launch_window = [&](const CompareArgs &aw) {
       if (h->rowsK)
       {
@@ -607,7 +688,9 @@ int launch_compare_fold(bioem_hip_ctx *h, const BatchBuf &bb, int nOC, int orien
         else
           hipLaunchKernelGGL(k_nyquist_rows<15>, gridq, dim3(256), 0, h->stream, aw);
       }
-      hipLaunchKernelGGL(fast_kernel(h->winD, 2 * h->fast, h->nyq, h->gs), grid, dim3(256), lds, h->stream, aw);
+      hipLaunchKernelGGL(h->fastm ? fastm_kernel(h->winD, 2 * h->fast, h->nyq, h->gs)
+                                  : fast_kernel(h->winD, 2 * h->fast, h->nyq, h->gs),
+                         grid, dim3(256), lds, h->stream, aw);
     };
     if (!h->tileT)
       launch_window(a);
@@ -987,7 +1070,9 @@ static int create_impl(bioem_hip_handle *out, int device, const bioem_hip_param_
   // column block is mostly empty (160^2 +-15 px 36.1 -> 43.9, 192^2 33.8 -> 38.1); at 200^2 / 224^2 / 240^2 the two tie
   // (31.5 / 33.6 / 29.8 vs 29.8 / 32.6 / 29.7) and at 96^2 the template wins (73.1 vs 67.8): those keep it
   const bool nyqSize0 = BIOEM_NYQUIST_SPLIT && N % 2 == 0 && (N / 2) % 64 == 0;
-  const bool midWindow = h->nd > 21 && h->nd <= 31 && (nyqSize0 || (h->H > 64 && h->H <= 100));
+  // (k_compare_fastm took these windows over; BIOEM_MID_WIDE2 brings the old choice back for A/B runs)
+  const bool midWindow = h->nd > 21 && h->nd <= 31 && (nyqSize0 || (h->H > 64 && h->H <= 100)) &&
+                         getenv("BIOEM_MID_WIDE2");
   if (N % 2 == 0 && N >= 8 && (mD > 15 || h->nd > 31 || midWindow || (getenv("BIOEM_FORCE_WIDE2") && h->nd >= 21)) &&
       h->nd == 2 * mD + 1 && !getenv("BIOEM_NO_WIDE2"))
   {
@@ -1247,6 +1332,27 @@ static int create_impl(bioem_hip_handle *out, int device, const bioem_hip_param_
     if (h->fast && h->winD == 5 && !h->tileT && ((nblkF >= 4 && h->fast <= 8) || h->N1 >= 40) && !getenv("BIOEM_KEEP_WD5"))
       h->winD = 10;
   }
+  // 23..31-row windows on even sizes: k_compare_fastm -- window pass on the matrix cores, register FFT of at most 16
+  // points (27/31 rows of T accumulators + a longer FFT do not fit three waves per SIMD)
+  if (!h->wide2 && h->fast && (h->winD > 10 || getenv("BIOEM_FASTM_ALL")) && !(h->tileT && h->wideWPC))
+  {
+    int R = 2 * h->fast;
+    if (R > 16 && !getenv("BIOEM_FASTM_R32"))
+    {
+      static const int lens[] = {16, 12, 10, 8, 6, 4, 2};
+      for (int l : lens)
+        if (N % l == 0 && (h->gs == 1 || (l & (l - 1)) == 0))
+        {
+          R = l;
+          break;
+        }
+    }
+    if (h->nyq && !getenv("BIOEM_FASTM_R32"))
+      R = 16; // (N / 2 a multiple of 64)
+    h->fast = R / 2;
+    h->N1 = N / R;
+    h->fastm = true;
+  }
   // no even factor (odd N) but a window of at most 31 rows: k_compare_rows (reference layout, direct column sums,
   // the fast kernel's T exchange / window / posterior) instead of the generic kernel
   h->rowsK = !h->fast && N >= 8 && (h->tileT || (mD <= 15 && h->nd <= 31)) && !getenv("BIOEM_NO_ROWS_KERNEL");
@@ -1274,7 +1380,8 @@ static int create_impl(bioem_hip_handle *out, int device, const bioem_hip_param_
     h->genericWaves = 4;
     while (!h->fast && h->genericWaves > 1 && compare_lds_bytes(N, h->H, h->nd, h->genericWaves) > 160 * 1024)
       h->genericWaves >>= 1;
-    const size_t lds = h->fast    ? fast_lds_bytes(N, 2 * h->winD + 1, 4, fast_half_t(h->winD, 2 * h->fast))
+    const size_t lds = h->fastm   ? fastm_lds_bytes(N)
+                       : h->fast  ? fast_lds_bytes(N, 2 * h->winD + 1, 4, fast_half_t(h->winD, 2 * h->fast))
                        : h->rowsK ? fast_lds_bytes(N, 2 * h->winD + 1, 4, false)
                                   : compare_lds_bytes(N, h->H, h->nd, h->genericWaves);
     if (lds > 160 * 1024)
@@ -1282,7 +1389,10 @@ static int create_impl(bioem_hip_handle *out, int device, const bioem_hip_param_
       h->err = "configuration exceeds the 160 KiB LDS budget of the comparison kernel";
       return 2;
     }
-    if (h->fast)
+    if (h->fastm)
+      HIP_CHECK(h, hipFuncSetAttribute(reinterpret_cast<const void *>(fastm_kernel(h->winD, 2 * h->fast, h->nyq, h->gs)),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
+    else if (h->fast)
       HIP_CHECK(h, hipFuncSetAttribute(reinterpret_cast<const void *>(fast_kernel(h->winD, 2 * h->fast, h->nyq, h->gs)),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
     else if (h->rowsK)
@@ -1307,11 +1417,25 @@ static int create_impl(bioem_hip_handle *out, int device, const bioem_hip_param_
     partCap = std::max<size_t>((size_t) nCTF, (1024u << 20) / ((size_t) nMaps * sizeof(Partial) * partBuffers));
   if (ocCap > partCap)
     ocCap = partCap;
+  // Few particles (BASELINE config 1: 10): a batch of 64 orientations is a comparison launch of a few thousand pairs
+  // behind a preparation whose duration is set by latencies, not work (the ordered Parseval sum of k_convolve is one
+  // sequential float chain per conv spectrum, bit-pinned to bioem.cpp:1896-1914) -- all chains of a batch run side by
+  // side, so the batch grows until one launch compares ~320 000 pairs (what 64 orientations are at 1 000 particles x 5
+  // CTFs); the conv buffer may then take 1 GiB per pipeline slot instead of 96 MiB.
+  int obMax = 64;
+  {
+    const long long perOrient = (long long) nCTF * nMaps;
+    if (perOrient * 64 < 320000 && !getenv("BIOEM_FIXED_BATCH"))
+    {
+      obMax = (int) std::min<long long>(2048, ((320000 + perOrient - 1) / perOrient + 63) / 64 * 64);
+      ocCap = std::min(partCap, (size_t) (1024u << 20) / (M * sizeof(float2)));
+    }
+  }
   int OB = (int) (ocCap / (size_t) nCTF);
   if (OB < 1)
     OB = 1;
-  if (OB > 64)
-    OB = 64;
+  if (OB > obMax)
+    OB = obMax;
   if (getenv("BIOEM_PCHUNK")) // tuning knob: particle chunk of the comparison kernel's block order
     h->pchunk = atoi(getenv("BIOEM_PCHUNK"));
   if (getenv("BIOEM_BATCH_ORIENTATIONS")) // tuning knob: orientations per batch (conv buffer = OB*nCTF spectra)
@@ -2190,6 +2314,8 @@ const char *bioem_hip_kernel_name(bioem_hip_handle h)
     return "";
   if (h->wide2)
     return "k_compare_wide2";
+  if (h->fastm)
+    return "k_compare_fastm";
   if (h->fast)
     return (h->tileT && h->wideWPC) ? "k_compare_wide" : "k_compare_fast";
   return h->rowsK ? (h->oddR ? "k_compare_oddfft" : "k_compare_rows") : "k_compare_generic";
@@ -2210,6 +2336,8 @@ const char *bioem_hip_kernel_signature(bioem_hip_handle h)
                2 * h->fast, h->w2NRW, h->w2NBLK, nq);
   else if (h->fast && h->tileT && h->wideWPC)
     snprintf(buf, sizeof(buf), "k_compare_wide<%d, %d, %d, %s>", 2 * h->fast, h->gs, h->wideWPC, nq);
+  else if (h->fastm)
+    snprintf(buf, sizeof(buf), "k_compare_fastm<%d, %d, %s, %d>", h->winD, 2 * h->fast, nq, h->gs);
   else if (h->fast)
     snprintf(buf, sizeof(buf), "k_compare_fast<%d, %d, %s, %d>", h->winD, 2 * h->fast, nq, h->gs);
   else if (h->rowsK && h->oddR)

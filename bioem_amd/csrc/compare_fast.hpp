@@ -87,6 +87,129 @@ __device__ __forceinline__ void lsef_wave_reduce(LseF &L)
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Posterior of a BATCH of B displacements of one lane (bioem_algorithm.h:18-123), written so that the B evaluations are
+// independent straight-line chains the scheduler can interleave (one basic block):
+//   * cc = acc / N^2 exactly as the reference divides (bioem_algorithm.h:163-164), but as q = a*r, q' = q + r*(a - q*b)
+//     with r = RN(1/b): correctly rounded for a correctly rounded reciprocal (Markstein), 3 instructions instead of the
+//     11 of the generic IEEE division sequence;
+//   * the log-table lookups of all B values are issued together; the exact slow path (non-positive / non-finite
+//     argument) is ONE wave-uniform branch per batch instead of a call site per value;
+//   * log-sum-exp per batch: the batch maximum first (first visited displacement wins among equal float maxima, as in
+//     lsef_push), ONE rescale of the running sum, then B independent exponentials.
+// ------------------------------------------------------------------------------------------------
+struct PostW
+{
+  float Np, nn, rnn; // Ntotpi, N^2 and RN(1 / N^2)
+  float k0, k1, k2, k3; // sumsqref*sumsquareC, 2*sumref*sumC, sumsqref*sumC*sumC, sumref*sumref*sumsquareC
+  double A, t2, prior;
+};
+
+__device__ __forceinline__ PostW post_consts(float Np, int N, const bioem_hip_param5 &q, float sumref, float sumsqref,
+                                             double t2, double prior)
+{
+  PostW w;
+  w.Np = Np;
+  w.nn = (float) (N * N);
+  w.rnn = 1.0f / w.nn;
+  // sub-expressions of bioem_algorithm.h:32-36 in the reference's association order
+  w.k0 = sumsqref * q.sumsquareC;
+  w.k1 = 2 * sumref * q.sumC;
+  w.k2 = sumsqref * q.sumC * q.sumC;
+  w.k3 = sumref * sumref * q.sumsquareC;
+  w.A = (double) (3 - Np) * 0.5;
+  w.t2 = t2;
+  w.prior = prior;
+  return w;
+}
+
+__device__ __forceinline__ float div_by_nn(float a, const PostW &w)
+{
+  const float q = a * w.rnn;
+  const float r = fmaf(-q, w.nn, a);
+  return fmaf(r, w.rnn, q);
+}
+
+template <int B>
+__device__ __forceinline__ void posterior_batch(LseF &L, const float (&acc)[B], const int (&id)[B], const bool (&ok)[B],
+                                                const PostW &w, const double2 *ltab, int algo)
+{
+  float cc[B], fe[B];
+  bool bad = false;
+#pragma unroll
+  for (int v = 0; v < B; v++)
+  {
+    cc[v] = div_by_nn(acc[v], w);
+    // bioem_algorithm.h:32-36, float expression in the reference's order
+    const float f = w.Np * (w.k0 - cc[v] * cc[v]) + w.k1 * cc[v] - w.k2 - w.k3;
+    fe[v] = ok[v] ? f : 1.f;
+    bad = bad || !(fe[v] > 1.1754944e-38f) || __float_as_uint(fe[v]) >= 0x7f800000u;
+  }
+  double lg[B];
+  if (__builtin_expect(__any(bad), 0))
+  { // some lane of the wave holds a non-positive / non-finite argument: the exact per-value path
+#pragma unroll
+    for (int v = 0; v < B; v++)
+      lg[v] = log_of_float(fe[v], ltab);
+  }
+  else
+  {
+    double2 t[B];
+#pragma unroll
+    for (int v = 0; v < B; v++)
+      t[v] = ltab[(__float_as_uint(fe[v]) >> 17) & 63];
+#pragma unroll
+    for (int v = 0; v < B; v++)
+    { // same arithmetic as log_of_float
+      const unsigned int bits = __float_as_uint(fe[v]);
+      const int e = (int) (bits >> 23) - 127;
+      const float m = __uint_as_float((bits & 0x007fffffu) | 0x3f800000u);
+      const double r = fma((double) m, t[v].x, -1.0);
+      double p = fma(r, -1.0 / 6.0, 1.0 / 5.0);
+      p = fma(r, p, -1.0 / 4.0);
+      p = fma(r, p, 1.0 / 3.0);
+      p = fma(r, p, -1.0 / 2.0);
+      p = fma(r * r, p, r);
+      lg[v] = fma((double) e, 0.693147180559945309417232, t[v].y + p);
+    }
+  }
+  float lpf[B];
+  double lpe[B];
+#pragma unroll
+  for (int v = 0; v < B; v++)
+  {
+    double lp = w.A * lg[v] + w.t2;
+    lp -= w.prior;
+    lpf[v] = ok[v] ? (float) lp : -INFINITY;
+    lpe[v] = (algo == 1) ? (double) lpf[v] : lp;
+  }
+  // batch maximum; among equal maxima the first VISITED displacement (smallest id) wins
+  float mb = lpf[0], vb = cc[0];
+  int ib = ok[0] ? id[0] : 0x7fffffff;
+#pragma unroll
+  for (int v = 1; v < B; v++)
+  {
+    const bool t = ok[v] && (lpf[v] > mb || (lpf[v] == mb && id[v] < ib));
+    mb = t ? lpf[v] : mb;
+    ib = t ? id[v] : ib;
+    vb = t ? cc[v] : vb;
+  }
+  const bool take = mb > L.m || (mb == L.m && ib < L.id);
+  const float newm = fmaxf(L.m, mb);
+  // running sum rescaled once (exp(-inf) = 0 restarts an empty sum; equal maxima: factor 1 without an exponential)
+  double sum = (L.m == newm) ? L.s : L.s * exp_fast_nonpos((double) L.m - (double) newm);
+#pragma unroll
+  for (int v = 0; v < B; v++)
+  {
+    const double e = exp_fast_nonpos(lpe[v] - (double) newm);
+    sum += ok[v] ? e : 0.;
+  }
+  L.s = sum;
+  L.m = newm;
+  L.id = take ? ib : L.id;
+  L.val = take ? vb : L.val;
+}
+
 // Window accumulation over one block of 64 frequency columns held in LDS as Tl[row = dx + WD][64] float2
 // (already weighted by 1 or 2 per column; zero beyond H).  lane = (iy, group); a group owns `nr` consecutive
 // displacement rows so that each LDS twiddle read E[ky*dy] feeds nr accumulators; T is read two columns

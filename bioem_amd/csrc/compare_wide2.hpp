@@ -271,7 +271,9 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? ((NRW * NBLK <= 26 && R <= 16) ?
           }
           W2_STAMP(10);
         }
+#ifndef BIOEM_W2_TIMING_NOBARRIER
         __syncthreads();
+#endif
         W2_STAMP(5);
         // fold the round's slots into this wave's rows:  T[dx] += w_N^(dx k1) * y_k1[dx mod R]
         // (all NRW accumulators; rows beyond this wave's share fold zeros and are never stored)
@@ -279,7 +281,11 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? ((NRW * NBLK <= 26 && R <= 16) ?
         for (int s = 0; s < NW; s++)
         {
           const int k1s = base + s;
+#ifdef BIOEM_W2_TIMING_NOFOLD
+          if (k1s < N1 && a.nd > 1000)
+#else
           if (k1s < N1)
+#endif
           {
             // this wave's NRW twiddles of step k1s are contiguous: a few wide scalar loads
             const const_float2_ptr twk = as_constant(a.twk) + ((size_t) k1s * NW + wave) * NRW;
@@ -319,18 +325,15 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? ((NRW * NBLK <= 26 && R <= 16) ?
             }
           }
         }
+#ifndef BIOEM_W2_TIMING_NOBARRIER
         __syncthreads();
+#endif
         W2_STAMP(6);
       }
     }
   }
   W2_STAMP(0);
-  const bioem_hip_param5 q = cst->q;
-  const float sumref = cst->sumref, sumsqref = cst->sumsqref;
-  const double t2 = cst->t2, prior = cst->prior;
-  const float Np = a.pd.Ntotpi;
-  const double A = (double) (3 - Np) * 0.5;
-  const float nn = (float) (N * N);
+  const PostW pw = post_consts(a.pd.Ntotpi, N, cst->q, cst->sumref, cst->sumsqref, cst->t2, cst->prior);
   LseF L;
   L.m = -INFINITY;
   L.s = 0.;
@@ -433,7 +436,10 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? ((NRW * NBLK <= 26 && R <= 16) ?
     // two row pairs per step: their recombination sums and the four log posteriors are independent chains that
     // overlap each other's LDS and double-precision latencies (two waves per SIMD hide little of them)
     // (measured: +4 % at +-40 px for the two-wave instantiations, -2..-4 % for the three-wave ones, which keep one pair)
-    constexpr int PPS = (NRW * NBLK <= 26 && R <= 16) ? 1 : 2;
+#ifndef BIOEM_W2_PPS
+#define BIOEM_W2_PPS 0
+#endif
+    constexpr int PPS = BIOEM_W2_PPS ? BIOEM_W2_PPS : (NRW * NBLK <= 26 && R <= 16) ? 1 : 2;
     // the lane's N1 - 1 recombination twiddles depend on dy only: for N1 <= 8 they are fetched once per chunk and
     // stay in registers over all row pairs (entries beyond N1 are zero and multiply a clamped, finite y)
 #ifndef BIOEM_W2_K1H
@@ -510,27 +516,20 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? ((NRW * NBLK <= 26 && R <= 16) ?
           }
         }
       }
-      float ccv[2 * PPS];
-      double lpv[2 * PPS];
+      W2_STAMP(11);
+      float accv[2 * PPS];
+      int idv[2 * PPS];
+      bool okv[2 * PPS];
 #pragma unroll
       for (int v = 0; v < 2 * PPS; v++)
       {
-        const float cc = ((v & 1) ? si[v >> 1] : sr[v >> 1]) / nn;
-        ccv[v] = cc;
-        // bioem_algorithm.h:32-36, float expression in the reference's order
-        const float firstele = Np * (sumsqref * q.sumsquareC - cc * cc) + 2 * sumref * q.sumC * cc -
-                               sumsqref * q.sumC * q.sumC - sumref * sumref * q.sumsquareC;
-        double lp = A * log_of_float(firstele, ltab) + t2;
-        lp -= prior;
-        lpv[v] = lp;
-      }
-#pragma unroll
-      for (int v = 0; v < 2 * PPS; v++)
-      {
+        accv[v] = (v & 1) ? si[v >> 1] : sr[v >> 1];
         const int m = h0 + 2 * pairs[v >> 1] + (v & 1);
-        if (pv[v >> 1] && m < nd)
-          lsef_push(L, lpv[v], dinv[m] * nd + iyr, ccv[v], a.algo);
+        okv[v] = pv[v >> 1] && m < nd;
+        idv[v] = dinv[min(m, nd - 1)] * nd + iyr;
       }
+      posterior_batch<2 * PPS>(L, accv, idv, okv, pw, ltab, a.algo);
+      W2_STAMP(12);
     }
   }
     if (hf + 1 < HALVES)

@@ -27,6 +27,10 @@ class ParamDevice(C.Structure):
 
 
 def lib_path():
+    # BIOEM_HIP_LIBRARY: an experiment build of the same library (scripts/slim_build.sh) for same-box A/B runs
+    alt = os.environ.get("BIOEM_HIP_LIBRARY")
+    if alt:
+        return alt if os.path.isabs(alt) else os.path.join(os.path.dirname(HERE), alt)
     return os.path.join(HERE, "lib", "libbioem_hip.so")
 
 

@@ -22,10 +22,11 @@ for it in range(2):
     L.bioem_hip_debug_w2_stamps(out)
 v = [int(x) for x in out]
 n = W.nOrient * W.nCTF * W.nP
-names = ["column pass: tail", "T -> LDS + barrier", "row FFT", "recombination + posterior", "wave reduce + barrier",
+names = ["column pass: tail", "T -> LDS + barrier", "row FFT", "recombination + posterior: rest (chunk set-up)", "wave reduce + barrier",
          "column: barrier after produce", "column: fold + barrier", "-", "column: loads + spectrum product",
-         "column: register FFT", "column: park outputs, request next F"]
-tot = sum(v[:11])
+         "column: register FFT", "column: park outputs, request next F", "recombination over k1 (in loop)",
+         "posterior batch (in loop)"]
+tot = sum(v[:13])
 print(E.kernel_signature, "comparisons", n)
-for k in (8, 9, 10, 5, 6, 0, 1, 2, 3, 4):
+for k in (8, 9, 10, 5, 6, 0, 1, 2, 11, 12, 3, 4):
     print("%-34s %8.0f cycles/comparison  %5.1f %%" % (names[k], v[k] / n, 100.0 * v[k] / tot))
