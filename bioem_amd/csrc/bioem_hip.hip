@@ -631,7 +631,12 @@ int launch_compare_fold(bioem_hip_ctx *h, const BatchBuf &bb, int nOC, int orien
   a.ndx = a.ndy = h->nd;
   a.pchunk = h->pchunk > 0 ? std::min(h->pchunk, h->nMaps) : h->nMaps;
   const int ocGroups = (nOC + 3) / 4;
-  const dim3 grid((unsigned) ((size_t) ocGroups * h->nMaps));
+  // few particles: whole groups per XCD (fast_block_pair); the grid is padded to a multiple of 8 groups
+  const bool groupPerXcd = h->nMaps <= 64 && h->fast && !h->wide2 && !(h->tileT && h->wideWPC) &&
+                           !getenv("BIOEM_NO_GROUP_XCD");
+  if (groupPerXcd)
+    a.pchunk = -1;
+  const dim3 grid((unsigned) ((size_t) (groupPerXcd ? (ocGroups + 7) / 8 * 8 : ocGroups) * h->nMaps));
   hipEvent_t e0 = get_event(h), e1 = get_event(h);
   if (!e0 || !e1)
   {
@@ -945,8 +950,13 @@ int compat_flush(bioem_hip_ctx *h)
 // conv spectra of CTFs [c0, c0 + nC) of the nO projected orientations, row ob * nC + (c - c0)
 int convolve_batch(bioem_hip_ctx *h, const BatchBuf &bb, hipStream_t st, int nO, int c0, int nC)
 {
+  const int M4 = (int) ((h->M + 3) & ~(size_t) 3);
   hipLaunchKernelGGL(k_convolve, dim3(nC, nO), dim3(256), 0, st, bb.specRef, h->dCTF, h->dCtfParam, h->N, h->H,
-                     h->fast, h->N1, c0, bb.conv, bb.scratch, bb.params);
+                     h->fast, h->N1, c0, bb.conv, bb.scratch, M4, bb.params);
+  HIP_CHECK(h, hipGetLastError());
+  // the ordered Parseval sums of all nC x nO spectra side by side: four sequential chains per wave
+  hipLaunchKernelGGL(k_parseval_ordered, dim3((nC * nO + 3) / 4), dim3(64), 0, st, bb.scratch, (int) h->M, M4, nC * nO,
+                     (float) (h->N * h->N), bb.params);
   HIP_CHECK(h, hipGetLastError());
   return 0;
 }
@@ -1460,7 +1470,7 @@ static int create_impl(bioem_hip_handle *out, int device, const bioem_hip_param_
   HIP_CHECK(h, hipMalloc(&h->dTempDen, sizeof(double) * h->chunkB));
   HIP_CHECK(h, hipMalloc(&h->dRowSpec, sizeof(double2) * (size_t) h->chunkB * M));
   HIP_CHECK(h, hipMalloc(&h->dSpecRef, sizeof(float2) * (size_t) h->chunkB * M));
-  HIP_CHECK(h, hipMalloc(&h->dScratch, sizeof(float) * (size_t) h->maxOC * M));
+  HIP_CHECK(h, hipMalloc(&h->dScratch, sizeof(float) * (size_t) ((h->maxOC + 31) & ~31) * ((M + 3) & ~(size_t) 3)));
   HIP_CHECK(h, hipMalloc(&h->dConv, sizeof(float2) * (size_t) h->maxOC * M));
   HIP_CHECK(h, hipMalloc(&h->dParams, sizeof(bioem_hip_param5) * h->maxOC));
   HIP_CHECK(h, hipMalloc(&h->dPostC, sizeof(double2) * h->maxOC));
@@ -1503,7 +1513,7 @@ static int create_impl(bioem_hip_handle *out, int device, const bioem_hip_param_
   HIP_CHECK(h, hipMalloc(&h->dTempDen2, sizeof(double) * h->OB));
   HIP_CHECK(h, hipMalloc(&h->dRowSpec2, sizeof(double2) * (size_t) h->OB * M));
   HIP_CHECK(h, hipMalloc(&h->dSpecRef2, sizeof(float2) * (size_t) h->OB * M));
-  HIP_CHECK(h, hipMalloc(&h->dScratch2, sizeof(float) * (size_t) h->maxOC * M));
+  HIP_CHECK(h, hipMalloc(&h->dScratch2, sizeof(float) * (size_t) ((h->maxOC + 31) & ~31) * ((M + 3) & ~(size_t) 3)));
   HIP_CHECK(h, hipMalloc(&h->dConv2, sizeof(float2) * (size_t) h->maxOC * M));
   HIP_CHECK(h, hipMalloc(&h->dParams2, sizeof(bioem_hip_param5) * h->maxOC));
   HIP_CHECK(h, hipMalloc(&h->dPostC2, sizeof(double2) * h->maxOC));
@@ -1585,6 +1595,16 @@ static int create_impl(bioem_hip_handle *out, int device, const bioem_hip_param_
       HIP_CHECK(h, hipMemcpy(h->dTwNyq, twn.data(), sizeof(float2) * twn.size(), hipMemcpyHostToDevice));
     }
   }
+  // BIOEM_SIGNATURE_LOG=<file>: one line per handle with the comparison-kernel instantiations its launches will use
+  // (scripts/check_kernel_coverage.py holds the lines of a test run against the kernels in the code object)
+  if (const char *lg = getenv("BIOEM_SIGNATURE_LOG"))
+    if (FILE *f = fopen(lg, "a"))
+    {
+      fprintf(f, "%s\n", bioem_hip_kernel_signature(h));
+      if (h->nyq)
+        fprintf(f, "k_nyquist_rows<%d>\n", h->wide2 ? h->nyqWD : (h->tileT && h->wideWPC) ? 10 : h->winD);
+      fclose(f);
+    }
   return 0;
 }
 

@@ -210,6 +210,37 @@ __device__ __forceinline__ void posterior_batch(LseF &L, const float (&acc)[B], 
   L.val = take ? vb : L.val;
 }
 
+// block -> (particle, group of 4 orientation*CTF).  Workgroups go round-robin over the 8 XCDs (each with its own L2).
+//   a.pchunk > 0: particle chunks of a.pchunk; inside a chunk the particle index runs fastest, then the group.  With a
+//     chunk size that is a multiple of 8 a particle always lands on the same XCD, and the ~96 blocks resident per XCD
+//     cover (pchunk/8 particles) x (a few groups): every particle line is then shared through that XCD's L2 by several
+//     groups and every conv line by pchunk/8 particles, instead of each particle line being fetched from Infinity
+//     Cache/HBM once per group.
+//   a.pchunk < 0 (few particles): group g goes to XCD g % 8 with ALL its particles (grid padded to a multiple of 8
+//     groups).  With 20 particles the chunk order would spread the 20 blocks of a group over all 8 XCDs, i.e. fetch
+//     every conv line into 8 L2s for 2.5 blocks each (measured: 8 GB per launch from the fabric, 33 M/s); the particle
+//     spectra are few enough to sit in every L2.
+__device__ __forceinline__ bool fast_block_pair(const CompareArgs &a, int &p, int &ocg)
+{
+  const int ocGroups = (a.nOC + 3) >> 2;
+  if (a.pchunk < 0)
+  {
+    const int x = blockIdx.x & 7, q = blockIdx.x >> 3;
+    ocg = (q / a.nMaps) * 8 + x;
+    p = q % a.nMaps;
+    return ocg < ocGroups;
+  }
+  const int per = a.pchunk * ocGroups;
+  int c = blockIdx.x / per;
+  const int nch = (a.nMaps + a.pchunk - 1) / a.pchunk;
+  c = min(c, nch - 1);
+  const int rem = blockIdx.x - c * per;
+  const int pc = min(a.pchunk, a.nMaps - c * a.pchunk);
+  ocg = rem / pc;
+  p = c * a.pchunk + (rem - ocg * pc);
+  return true;
+}
+
 // Window accumulation over one block of 64 frequency columns held in LDS as Tl[row = dx + WD][64] float2
 // (already weighted by 1 or 2 per column; zero beyond H).  lane = (iy, group); a group owns `nr` consecutive
 // displacement rows so that each LDS twiddle read E[ky*dy] feeds nr accumulators; T is read two columns
@@ -358,17 +389,8 @@ __global__ __launch_bounds__(256, fast_waves_per_simd(WD, R)) void k_compare_fas
   // groups and every conv line by pchunk/8 particles, instead of each particle line being fetched from Infinity
   // Cache/HBM once per group.
   int p, ocg;
-  {
-    const int ocGroups = (a.nOC + 3) >> 2;
-    const int per = a.pchunk * ocGroups;
-    int c = blockIdx.x / per;
-    const int nch = (a.nMaps + a.pchunk - 1) / a.pchunk;
-    c = min(c, nch - 1);
-    const int rem = blockIdx.x - c * per;
-    const int pc = min(a.pchunk, a.nMaps - c * a.pchunk);
-    ocg = rem / pc;
-    p = c * a.pchunk + (rem - ocg * pc);
-  }
+  if (!fast_block_pair(a, p, ocg))
+    return;
   const int oc_raw = ocg * 4 + wave;
   const bool oc_valid = oc_raw < a.nOC;
   const int oc = oc_valid ? oc_raw : a.nOC - 1;

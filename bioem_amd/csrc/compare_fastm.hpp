@@ -81,19 +81,9 @@ __global__ __launch_bounds__(256, 3) void k_compare_fastm(const CompareArgs a)
   }
   __syncthreads();
 
-  // block -> (particle, group of 4 orientation*CTF): the XCD-aware order of k_compare_fast
   int p, ocg;
-  {
-    const int ocGroups = (a.nOC + 3) >> 2;
-    const int per = a.pchunk * ocGroups;
-    int c = blockIdx.x / per;
-    const int nch = (a.nMaps + a.pchunk - 1) / a.pchunk;
-    c = min(c, nch - 1);
-    const int rem = blockIdx.x - c * per;
-    const int pc = min(a.pchunk, a.nMaps - c * a.pchunk);
-    ocg = rem / pc;
-    p = c * a.pchunk + (rem - ocg * pc);
-  }
+  if (!fast_block_pair(a, p, ocg)) // the XCD-aware block order of k_compare_fast
+    return;
   const int oc_raw = ocg * 4 + wave;
   const bool oc_valid = oc_raw < a.nOC;
   const int oc = oc_valid ? oc_raw : a.nOC - 1;

@@ -304,8 +304,16 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? ((NRW * NBLK <= 26 && R <= 16) ?
               for (int e = 0; e < FC; e++)
               {
                 const int d = d0 + e < NRW ? d0 + e : NRW - 1;
+#ifdef BIOEM_W2_TIMING_ONETW
+                w[e] = make_float2(twk[0].x, twk[0].y); // timing only: one scalar load per slot instead of NRW
+#else
                 w[e] = make_float2(twk[d].x, twk[d].y);
+#endif
+#ifdef BIOEM_W2_TIMING_ONEY
+                y[e] = ys[yoff[0]];                     // timing only: one LDS read per slot
+#else
                 y[e] = YOFF_REGS ? ys[yoff[YOFF_REGS ? d : 0]] : ys[((res0 + d * gs) % R) * 64 + lane];
+#endif
               }
 #pragma unroll
               for (int e = 0; e < FC; e++)

@@ -297,26 +297,29 @@ __global__ void k_map_sums(const float *__restrict__ maps, int NN, float *__rest
 
 // ------------------------------------------------------------------------------------------------
 // convolution: bioem.cpp:1855-1923.  grid (CTFs of the launch, nOrientInBatch); CTF index = c0 + blockIdx.x.
-// sumsquareC is accumulated sequentially in float in the reference's order (rows; inside a row the
-// interior columns doubled, then column 0, then column N/2 for even N): the terms are produced in
-// parallel into `scratch` in that order and summed by one lane.
+// k_convolve forms conv = proj * conj(CTF) in the comparison layout, sumC, and the terms of sumsquareC in the
+// reference's summation order (rows; inside a row the interior columns doubled, then column 0, then column N/2 for
+// even N) in `scratch` (row stride M4 = M rounded up to 4 floats).  The sum itself is a SEQUENTIAL float chain in the
+// reference (bioem.cpp:1896-1914) and bit-pinned to it: ~7 cycles per term whatever is done.  k_parseval_ordered makes
+// the chains cheap to run side by side: one WAVE carries four chains (lanes 0..3 add, one spectrum each) and feeds
+// itself -- all 64 lanes fetch the four spectra's next tiles of 512 terms with coalesced 16-byte loads, two tiles
+// ahead, and pass them through 16 KiB of LDS -- so ten waves (40 chains) fit a CU and a batch of 10 000 spectra takes
+// about one chain's duration (before: one block of four waves and 32 KiB per chain, 1 280 chains in flight).
 // ------------------------------------------------------------------------------------------------
 __global__ void k_convolve(const float2 *__restrict__ proj, const float2 *__restrict__ ctf,
                            const float *__restrict__ ctfParam, int N, int H, int fast, int N1, int c0,
-                           float2 *__restrict__ conv, float *__restrict__ scratch,
+                           float2 *__restrict__ conv, float *__restrict__ scratch, int M4,
                            bioem_hip_param5 *__restrict__ params)
 {
-  __shared__ __align__(16) float buf[2][4096];
   const int c = c0 + blockIdx.x, ob = blockIdx.y;
   const int oc = ob * gridDim.x + blockIdx.x;
   const int M = N * H;
   const float2 *P = proj + (size_t) ob * M;
   const float2 *K = ctf + (size_t) c * M;
   float2 *O = conv + (size_t) oc * M;
-  float *S = scratch + (size_t) oc * M;
+  float *S = scratch + (size_t) oc * M4;
   const int even = ((N & 1) == 0);
   const int jend = even ? H - 1 : H;
-  float sumC = 0.f;
   for (int e = threadIdx.x; e < M; e += blockDim.x)
   {
     const int i = e / H, j = e - i * H;
@@ -336,58 +339,88 @@ __global__ void k_convolve(const float2 *__restrict__ proj, const float2 *__rest
       pos = i * H + jend; // j == H-1, even N
     S[pos] = (j >= 1 && j < jend) ? t * 2 : t;
     if (e == 0)
-      sumC = o.x;
-  }
-  __syncthreads();
-  __threadfence_block();
-  // one lane adds the terms in order (the float rounding of the reference's loop); waves 1..3 stage the next 4 096
-  // terms into the other half of `buf` meanwhile, and the adding lane reads four terms per LDS access
-  float ss = 0.f;
-  const int wave = threadIdx.x >> 6;
-  for (int t = threadIdx.x; t < min(4096, M); t += blockDim.x)
-    buf[0][t] = S[t];
-  __syncthreads();
-  for (int base = 0, b = 0; base < M; base += 4096, b ^= 1)
-  {
-    const int cnt = min(4096, M - base);
-    if (wave != 0)
     {
-      const int nb = base + 4096;
-      if (nb < M)
-      {
-        const int cntn = min(4096, M - nb);
-        for (int t = threadIdx.x - 64; t < cntn; t += blockDim.x - 64)
-          buf[b ^ 1][t] = S[nb + t];
-      }
+      bioem_hip_param5 r;
+      r.amp = ctfParam[3 * c + 0];
+      r.pha = ctfParam[3 * c + 1];
+      r.env = ctfParam[3 * c + 2];
+      r.sumC = o.x;
+      r.sumsquareC = 0.f; // k_parseval_ordered
+      params[oc] = r;
     }
-    else if (threadIdx.x == 0)
+  }
+}
+
+__global__ __launch_bounds__(64) void k_parseval_ordered(const float *__restrict__ scratch, int M, int M4, int nSpec,
+                                                          float norm2, bioem_hip_param5 *__restrict__ params)
+{
+  constexpr int CH = 4;        // chains per wave
+  constexpr int TILE = 512;    // terms per chain and tile
+  constexpr int TS = TILE + 4; // chain stride in LDS (floats): the four adding lanes read different banks
+  __shared__ __align__(16) float buf[2][CH][TS];
+  const int lane = threadIdx.x;
+  const int oc0 = blockIdx.x * CH;
+  const int n4 = M >> 2; // whole float4 per spectrum; the last M % 4 terms are added at the end
+  const int nt = (n4 + TILE / 4 - 1) / (TILE / 4);
+  // load j of a tile (0..7): chain j / 2, float4 (j % 2) * 64 + lane of the tile
+  auto fetch = [&](int tile, float4 (&dst)[2 * CH]) {
+#pragma unroll
+    for (int j = 0; j < 2 * CH; j++)
     {
-      const float4 *q = reinterpret_cast<const float4 *>(buf[b]);
-      const int n4 = cnt >> 2;
+      const int c = j >> 1, f = tile * (TILE / 4) + (j & 1) * 64 + lane;
+      const int oc = min(oc0 + c, nSpec - 1);
+      dst[j] = f < n4 ? reinterpret_cast<const float4 *>(scratch + (size_t) oc * M4)[f] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+  float4 pre0[2 * CH], pre1[2 * CH];
+  fetch(0, pre0);
+  if (nt > 1)
+    fetch(1, pre1);
+  float ss = 0.f;
+  for (int i = 0; i < nt; i++)
+  {
+    const int b = i & 1;
+    // (the previous tile in this buffer was consumed two iterations ago; LDS operations of one wave execute in order)
+    if (b == 0)
+    {
+#pragma unroll
+      for (int j = 0; j < 2 * CH; j++)
+        *reinterpret_cast<float4 *>(&buf[0][j >> 1][((j & 1) * 64 + lane) * 4]) = pre0[j];
+      if (i + 2 < nt)
+        fetch(i + 2, pre0);
+    }
+    else
+    {
+#pragma unroll
+      for (int j = 0; j < 2 * CH; j++)
+        *reinterpret_cast<float4 *>(&buf[1][j >> 1][((j & 1) * 64 + lane) * 4]) = pre1[j];
+      if (i + 2 < nt)
+        fetch(i + 2, pre1);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    if (lane < CH)
+    { // the reference's order: one term after the other (tiles beyond the spectrum hold zeros: x + 0 = x)
+      const float4 *q = reinterpret_cast<const float4 *>(&buf[b][lane][0]);
 #pragma unroll 8
-      for (int t = 0; t < n4; t++)
+      for (int k = 0; k < TILE / 4; k++)
       {
-        const float4 v = q[t];
+        const float4 v = q[k];
         ss += v.x;
         ss += v.y;
         ss += v.z;
         ss += v.w;
       }
-      for (int t = n4 << 2; t < cnt; t++)
-        ss += buf[b][t];
     }
-    __syncthreads();
+    __builtin_amdgcn_wave_barrier();
   }
-  if (threadIdx.x == 0)
+  if (lane < CH && oc0 + lane < nSpec)
   {
-    bioem_hip_param5 r;
-    r.amp = ctfParam[3 * c + 0];
-    r.pha = ctfParam[3 * c + 1];
-    r.env = ctfParam[3 * c + 2];
-    r.sumC = sumC;
-    const float norm2 = (float) (N * N);
-    r.sumsquareC = ss / norm2;
-    params[oc] = r;
+    const float *row = scratch + (size_t) (oc0 + lane) * M4;
+    for (int e = n4 << 2; e < M; e++)
+      ss += row[e];
+    params[oc0 + lane].sumsquareC = ss / norm2;
   }
 }
 

@@ -29,6 +29,15 @@ def _ensure_built():
 
 def pytest_sessionstart(session):
     _ensure_built()
+    # every engine handle created during the run (this process and the CLI children) records the comparison-kernel
+    # instantiation it selected: scripts/check_kernel_coverage.py compares the record with the code object
+    log = os.path.join(ROOT, "gpurun_out", "kernel_signatures_run.txt")
+    try:
+        os.makedirs(os.path.dirname(log), exist_ok=True)
+        open(log, "w").close()
+        os.environ.setdefault("BIOEM_SIGNATURE_LOG", log)
+    except OSError:
+        pass
 
 
 @pytest.fixture(scope="session")
