@@ -6,21 +6,27 @@
 //
 //   prep_kernels.hpp     k_project        model points -> real-space projection (double atomics), one launch per batch
 //                        k_dft_rows/cols  r2c of the projections (exact DFT, double accumulation; off the critical path)
-//                        k_convolve       proj * conj(CTF) -> conv spectra in the comparison layout, sumC, sumsquareC
+//                        k_convolve       proj * conj(CTF) -> conv spectra in the comparison layout, sumC, Parseval terms
+//                        k_parseval_ordered  sumsquareC: the reference's sequential float sum, four chains per wave
 //                        k_reorder, k_map_sums: particle-side precompute
-//   compare_fast.hpp     k_compare_fast   one WAVE per (particle, orientation*CTF) comparison:
+//   compare_fast.hpp     k_compare_fast   windows of at most 21 rows; one WAVE per (particle, orientation*CTF) comparison:
 //                          spectrum product -> pruned inverse 2-D transform -> displacement-window log posterior
 //                          -> wave log-sum-exp/arg-max partial.  The length-N inverse along kx is split as
-//                          N = N1*R (R = 32, 16, 8, 4, 2): N1 register-resident R-point FFTs per frequency column
-//                          (lane = column, fft_registers.hpp), recombined only for the window rows that are
-//                          consumed (output pruning), so no radix-7 butterfly is ever needed for N = 224.  The
+//                          N = N1*R (R = 32, 16, 8, 4, 2 or a mixed length): N1 register-resident R-point FFTs per
+//                          frequency column (lane = column, fft_registers.hpp), recombined only for the window rows that
+//                          are consumed (output pruning), so no radix-7 butterfly is ever needed for N = 224.  The
 //                          transform along ky is a pruned real DFT evaluated from LDS for the window only.
 //                        k_nyquist_rows   the Nyquist column of 128^2 / 256^2 by direct summation
-//   compare_wide.hpp     k_compare_wide   wide windows: 2 or 4 waves per comparison share the column transforms, one
-//                          y-tile of the window per wave (tiles: window_tiles.hpp)
+//                        posterior_batch  the log posterior of a batch of displacements (all comparison kernels)
+//   compare_fastm.hpp    k_compare_fastm  27- / 31-row windows: the same column pass, the window pass as one 32 x 32 tile of
+//                          v_mfma_f32_32x32x2_f32 (exact f32) per comparison on the matrix cores
+//   compare_wide2.hpp    k_compare_wide2  wide windows (32..128 rows): four or eight waves per comparison share the
+//                          column transforms through LDS, row FFT over row pairs
 //   compare_rows.hpp     k_compare_oddfft / k_compare_rows  odd image sizes: register FFT of odd length (3..25) over the
 //                          reference layout, or direct column sums when N has no factor 3 or 5
-//   compare_generic.hpp  k_compare_generic  same maths for odd N / very wide windows (direct pruned DFT)
+//   compare_generic.hpp  k_compare_generic  same maths by direct pruned DFT (irregular wide displacement sets, N < 8)
+//   window_tiles.hpp     k_phase_shift, k_merge_tiles  wide windows no kernel covers: tiles of a window kernel
+//   kernel_select.hpp    kernel table, k_compare_wide2 rules, plan_kernels: which kernel runs which shape
 //   posterior.hpp        calc_logpro / calProb semantics (bioem_algorithm.h:18-142)
 //   fold_kernels.hpp     k_fold_wave, k_fold_angles (k_fold: serial variant): fold the per-comparison partials into the probability block in the
 //                          reference's (orientation, CTF) order (bioem_algorithm.h:96-123, bioem.cpp:1527-1600)
@@ -105,7 +111,9 @@ struct bioem_hip_ctx
   int tileT = 0, tilesPerAxis = 1;
   std::vector<int> tileCenter, tileValid; // per axis tile: centre (in window rows) and number of rows inside the window
   int *dDispLocal = nullptr, *dTileCenter = nullptr, *dTileValid = nullptr, *dRankOfRow = nullptr;
-  int wideWPC = 0; // k_compare_wide: waves per comparison (= y-tiles per launch), 0 = one launch per tile
+  const void *fn = nullptr; // the comparison kernel of this handle (fast_kernel_t, kernel_select.hpp)
+  size_t ldsBytes = 0;      // its dynamic LDS per block
+  int family = 0;           // KernelFamily
   // k_compare_wide2 (compare_wide2.hpp): wide window in ONE launch per batch -- column transforms shared by the four
   // waves of a comparison, row FFT
   bool wide2 = false;
@@ -208,11 +216,11 @@ struct bioem_hip_ctx
 #include "fft_registers.hpp"
 #include "compare_args.hpp"
 #include "compare_fast.hpp"
-#include "compare_wide.hpp"
 #include "compare_wide2.hpp"
 #include "compare_fastm.hpp"
 #include "compare_generic.hpp"
 #include "compare_rows.hpp"
+#include "kernel_select.hpp"
 #include "fold_kernels.hpp"
 #include "window_tiles.hpp"
 
@@ -226,18 +234,6 @@ namespace
 // ------------------------------------------------------------------------------------------------
 // host helpers
 // ------------------------------------------------------------------------------------------------
-size_t compare_lds_bytes(int N, int H, int NW, int waves)
-{ // generic kernel: tables + per-wave T [nd rows][Hs]
-  const int Hs = (H + 1) & ~1;
-  const size_t dispBytes = ((size_t) NW * 4 + 255) & ~(size_t) 255;
-  return (size_t) ((N + 2) & ~1) * 8 + dispBytes + (size_t) waves * NW * Hs * 8;
-}
-
-size_t fast_lds_bytes(int N, int NW, int waves, bool half)
-{ // fast kernel: twiddles + displacement list + log table + per-wave T block [NW][66] ([NW][34] with half exchange)
-  return (size_t) ((N + 2) & ~1) * 8 + 256 + 1024 + (size_t) waves * NW * (half ? 34 : 66) * 8;
-}
-
 hipEvent_t get_event(bioem_hip_ctx *h)
 {
   if (!h->evPool.empty())
@@ -287,317 +283,6 @@ BatchBuf batch_buf(bioem_hip_ctx *h, int which)
   return b;
 }
 
-// the fast-kernel instantiation for a window half width (10 or 15) and register-FFT length (32, 16, 8)
-typedef void (*fast_kernel_t)(const CompareArgs);
-#ifndef BIOEM_SLIM
-template <int WD, int GS>
-fast_kernel_t fast_kernel_r(int R, bool nyq)
-{
-  if (nyq) // N/2 a multiple of 64 implies R = 32
-    return k_compare_fast<WD, 32, true, GS>;
-  if constexpr (GS == 1)
-  { // mixed-radix register FFTs (unit window stride only)
-    switch (R)
-    {
-    case 6: return k_compare_fast<WD, 6, false, 1>;
-    case 10: return k_compare_fast<WD, 10, false, 1>;
-    case 12: return k_compare_fast<WD, 12, false, 1>;
-    case 18: return k_compare_fast<WD, 18, false, 1>;
-    case 20: return k_compare_fast<WD, 20, false, 1>;
-    case 30: return k_compare_fast<WD, 30, false, 1>;
-    default: break;
-    }
-  }
-  return R == 32   ? k_compare_fast<WD, 32, false, GS>
-         : R == 16 ? k_compare_fast<WD, 16, false, GS>
-         : R == 8  ? k_compare_fast<WD, 8, false, GS>
-         : R == 4  ? k_compare_fast<WD, 4, false, GS>
-                   : k_compare_fast<WD, 2, false, GS>;
-}
-
-template <int WD>
-fast_kernel_t fast_kernel_g(int R, bool nyq, int gs)
-{
-  return gs == 1 ? fast_kernel_r<WD, 1>(R, nyq) : gs == 2 ? fast_kernel_r<WD, 2>(R, nyq)
-         : gs == 3 ? fast_kernel_r<WD, 3>(R, nyq) : fast_kernel_r<WD, 4>(R, nyq);
-}
-
-// k_compare_wide instantiations: every register-FFT length of the fast kernel, row stride 1/2 (mixed radix: 1), 2 or 4
-// waves per comparison
-template <int R, bool NYQ>
-fast_kernel_t wide_kernel_r(int gs, int wpc)
-{
-  if (gs == 1)
-    return wpc == 2 ? k_compare_wide<R, 1, 2, NYQ> : k_compare_wide<R, 1, 4, NYQ>;
-  return wpc == 2 ? k_compare_wide<R, 2, 2, NYQ> : k_compare_wide<R, 2, 4, NYQ>;
-}
-#endif // BIOEM_SLIM
-fast_kernel_t wide_kernel(int R, int gs, int wpc, bool nyq)
-{
-#ifdef BIOEM_SLIM
-  return nullptr;
-#else
-  if (nyq) // N/2 a multiple of 64 implies R = 32
-    return wide_kernel_r<32, true>(gs, wpc);
-  switch (R)
-  {
-  case 32: return wide_kernel_r<32, false>(gs, wpc);
-  case 16: return wide_kernel_r<16, false>(gs, wpc);
-  case 8: return wide_kernel_r<8, false>(gs, wpc);
-  case 4: return wide_kernel_r<4, false>(gs, wpc);
-  case 2: return wide_kernel_r<2, false>(gs, wpc);
-  // mixed-radix lengths are only chosen with a unit row stride
-  case 30: return wpc == 2 ? k_compare_wide<30, 1, 2, false> : k_compare_wide<30, 1, 4, false>;
-  case 20: return wpc == 2 ? k_compare_wide<20, 1, 2, false> : k_compare_wide<20, 1, 4, false>;
-  case 18: return wpc == 2 ? k_compare_wide<18, 1, 2, false> : k_compare_wide<18, 1, 4, false>;
-  case 12: return wpc == 2 ? k_compare_wide<12, 1, 2, false> : k_compare_wide<12, 1, 4, false>;
-  case 10: return wpc == 2 ? k_compare_wide<10, 1, 2, false> : k_compare_wide<10, 1, 4, false>;
-  default: return wpc == 2 ? k_compare_wide<6, 1, 2, false> : k_compare_wide<6, 1, 4, false>;
-  }
-#endif
-}
-size_t wide_lds_bytes(int N, int H, int wpc, bool nyq)
-{ // tables + per comparison one T block [21][66] per 64-column block
-  const int nblk = nyq ? (H - 1) / 64 : (H + 63) / 64;
-  return (size_t) ((N + 2) & ~1) * 8 + 256 + 1024 + (size_t) (4 / wpc) * nblk * 21 * 66 * 8;
-}
-
-#ifndef BIOEM_SLIM
-// k_compare_wide2 instantiations: every register-FFT length; (rows per wave, column blocks) = (32, 1) or (21, 2)
-template <int R>
-fast_kernel_t wide2_kernel_r(int nblk, bool nyq, int halves)
-{
-  if constexpr (R == 32)
-  {
-    if (nyq && nblk == 3) // 384
-      return halves == 2 ? k_compare_wide2<32, 21, 3, true, 2> : k_compare_wide2<32, 21, 3, true>;
-    if (nyq)
-      return nblk == 1     ? k_compare_wide2<32, 32, 1, true>
-             : halves == 2 ? k_compare_wide2<32, 21, 2, true, 2>
-                           : k_compare_wide2<32, 21, 2, true>;
-  }
-  if constexpr (R == 32 || R == 16 || R == 8 || R == 30 || R == 20 || R == 12 || R == 10)
-  {
-    if (nblk == 3) // 256 < N <= 382
-      return halves == 2 ? k_compare_wide2<R, 21, 3, false, 2> : k_compare_wide2<R, 21, 3, false>;
-  }
-  return nblk == 1 ? k_compare_wide2<R, 32, 1, false> : halves == 2 ? k_compare_wide2<R, 21, 2, false, 2>
-                                                                    : k_compare_wide2<R, 21, 2, false>;
-}
-// windows of 32..52 rows (at most 11 / 13 per wave) over two column blocks with 16- or 8-point register FFTs: 44 / 52 T
-// accumulators + a short FFT fit three waves per SIMD, the T block (<= 48 KiB) three blocks per CU
-// one column block (N <= 126, or 128 with the Nyquist split), at most 21 rows per wave, 16- / 8-point FFTs: 42 T
-// accumulators -> three waves per SIMD as well
-fast_kernel_t wide2_kernel_small1(int R, bool nyq)
-{
-  if (nyq)
-    return k_compare_wide2<16, 21, 1, true>;
-  switch (R)
-  {
-  case 8: return k_compare_wide2<8, 21, 1, false>;
-  case 12: return k_compare_wide2<12, 21, 1, false>;
-  case 10: return k_compare_wide2<10, 21, 1, false>;
-  default: return k_compare_wide2<16, 21, 1, false>;
-  }
-}
-template <int NRW>
-fast_kernel_t wide2_kernel_small_n(int R, bool nyq)
-{
-  if (nyq) // N/2 a multiple of 64 (256^2): R = 16 by choice
-    return k_compare_wide2<16, NRW, 2, true>;
-  switch (R)
-  {
-  case 8: return k_compare_wide2<8, NRW, 2, false>;
-  case 12: return k_compare_wide2<12, NRW, 2, false>;
-  case 10: return k_compare_wide2<10, NRW, 2, false>;
-  default: return k_compare_wide2<16, NRW, 2, false>;
-  }
-}
-fast_kernel_t wide2_kernel_small(int R, int nrw, bool nyq)
-{
-  return nrw == 13 ? wide2_kernel_small_n<13>(R, nyq) : wide2_kernel_small_n<11>(R, nyq);
-}
-// 22..24 rows per wave (windows of 85..96 rows: +-42 ... +-47 px) over two column blocks, 32- / 16-point FFTs
-fast_kernel_t wide2_kernel_24(int R, bool nyq, int halves)
-{
-  if (R == 32 && nyq)
-    return halves == 2 ? k_compare_wide2<32, 24, 2, true, 2> : k_compare_wide2<32, 24, 2, true>;
-  if (R == 32)
-    return halves == 2 ? k_compare_wide2<32, 24, 2, false, 2> : k_compare_wide2<32, 24, 2, false>;
-  return halves == 2 ? k_compare_wide2<16, 24, 2, false, 2> : k_compare_wide2<16, 24, 2, false>;
-}
-// four column blocks (384 < N <= 512) with at most 11 rows per wave (windows of 32..44 rows), 32- / 16-point FFTs
-fast_kernel_t wide2_kernel_4(int R, bool nyq, int halves)
-{
-  if (R == 32 && nyq)
-    return halves == 2 ? k_compare_wide2<32, 11, 4, true, 2> : k_compare_wide2<32, 11, 4, true>;
-  if (R == 32)
-    return halves == 2 ? k_compare_wide2<32, 11, 4, false, 2> : k_compare_wide2<32, 11, 4, false>;
-  return halves == 2 ? k_compare_wide2<16, 11, 4, false, 2> : k_compare_wide2<16, 11, 4, false>;
-}
-fast_kernel_t wide2_kernel(int R, int nblk, bool nyq, int halves = 1, int nrw = 21)
-{
-  if (nblk == 4)
-    return wide2_kernel_4(R, nyq, halves);
-  if (nrw == 24)
-    return wide2_kernel_24(R, nyq, halves);
-  switch (R)
-  {
-  case 32: return wide2_kernel_r<32>(nblk, nyq, halves);
-  case 16: return wide2_kernel_r<16>(nblk, nyq, halves);
-  case 8: return wide2_kernel_r<8>(nblk, nyq, halves);
-  case 4: return wide2_kernel_r<4>(nblk, nyq, halves);
-  case 2: return wide2_kernel_r<2>(nblk, nyq, halves);
-  case 30: return wide2_kernel_r<30>(nblk, nyq, halves);
-  case 20: return wide2_kernel_r<20>(nblk, nyq, halves);
-  case 18: return wide2_kernel_r<18>(nblk, nyq, halves);
-  case 12: return wide2_kernel_r<12>(nblk, nyq, halves);
-  case 10: return wide2_kernel_r<10>(nblk, nyq, halves);
-  default: return wide2_kernel_r<6>(nblk, nyq, halves);
-  }
-}
-// the instantiation for a selection (create sets the attributes of the SAME function the launch uses)
-// eight waves per comparison: 16- / 12- / 10- / 8-point FFTs, 11 rows per wave, two column blocks, whole T block
-fast_kernel_t wide2_kernel_w8(int R, bool nyq)
-{
-  if (nyq)
-    return k_compare_wide2<16, 11, 2, true, 1, 8>;
-  switch (R)
-  {
-  case 12: return k_compare_wide2<12, 11, 2, false, 1, 8>;
-  case 10: return k_compare_wide2<10, 11, 2, false, 1, 8>;
-  case 8: return k_compare_wide2<8, 11, 2, false, 1, 8>;
-  default: return k_compare_wide2<16, 11, 2, false, 1, 8>;
-  }
-}
-// ... over four column blocks (384 < N <= 512), windows of 45..88 rows: one 512-thread block per CU
-fast_kernel_t wide2_kernel_w8_4(int R, bool nyq, int halves)
-{
-  if (R == 32 && nyq)
-    return halves == 2 ? k_compare_wide2<32, 11, 4, true, 2, 8> : k_compare_wide2<32, 11, 4, true, 1, 8>;
-  if (R == 32)
-    return halves == 2 ? k_compare_wide2<32, 11, 4, false, 2, 8> : k_compare_wide2<32, 11, 4, false, 1, 8>;
-  return halves == 2 ? k_compare_wide2<16, 11, 4, false, 2, 8> : k_compare_wide2<16, 11, 4, false, 1, 8>;
-}
-#endif // BIOEM_SLIM
-fast_kernel_t wide2_pick(int R, int nrw, int nblk, bool nyq, int halves, int nw = 4)
-{
-#ifdef BIOEM_SLIM
-#ifdef BIOEM_SLIM_W2
-  return k_compare_wide2<BIOEM_SLIM_W2>;
-#else
-  return nullptr;
-#endif
-#else
-  if (nw == 8 && nblk == 4)
-    return wide2_kernel_w8_4(R, nyq, halves);
-  if (nw == 8)
-    return wide2_kernel_w8(R, nyq);
-  if (nblk == 1 && nrw == 21)
-    return wide2_kernel_small1(R, nyq);
-  if (nblk == 2 && nrw <= 13)
-    return wide2_kernel_small(R, nrw, nyq);
-  return wide2_kernel(R, nblk, nyq, halves, nrw);
-#endif
-}
-size_t wide2_lds_bytes(int N, int R, int rows2, int ts, int nw = 4)
-{ // tables (twiddles, visiting ranks, log table, wave results, posterior constants) + max(one FFT-output slot per wave, T block)
-  const size_t slots = (size_t) nw * R * 64 * 8, tblock = (size_t) rows2 * ts * 8;
-  return (size_t) ((N + 2) & ~1) * 8 + 512 + 1024 + 256 + std::max(slots, tblock);
-}
-
-// k_compare_fastm instantiations: 27- and 31-row windows, register-FFT lengths up to 16 (three waves per SIMD), row strides
-// 1..4 for the power-of-two lengths, Nyquist split with 16 points
-size_t fastm_lds_bytes(int N)
-{ // cos / sin planes of the twiddle table (padded), window ranks, log table, per wave two 32 x 33 float planes and the
-  // resting place of the 16 tile accumulators
-  return (size_t) 2 * fastm_table_floats(N) * 4 + 128 + 1024 + (size_t) 4 * 2 * 32 * 33 * 4 + (size_t) 4 * 16 * 64 * 4;
-}
-#ifndef BIOEM_SLIM
-template <int WD, int GS>
-fast_kernel_t fastm_kernel_r(int R, bool nyq)
-{
-  if (nyq)
-    return k_compare_fastm<WD, 16, true, GS>;
-  if constexpr (GS == 1)
-  {
-    switch (R)
-    {
-    case 6: return k_compare_fastm<WD, 6, false, 1>;
-    case 10: return k_compare_fastm<WD, 10, false, 1>;
-    case 12: return k_compare_fastm<WD, 12, false, 1>;
-    default: break;
-    }
-  }
-  return R == 16 ? k_compare_fastm<WD, 16, false, GS>
-         : R == 8 ? k_compare_fastm<WD, 8, false, GS>
-         : R == 4 ? k_compare_fastm<WD, 4, false, GS>
-                  : k_compare_fastm<WD, 2, false, GS>;
-}
-template <int WD>
-fast_kernel_t fastm_kernel_g(int R, bool nyq, int gs)
-{
-  return gs == 1 ? fastm_kernel_r<WD, 1>(R, nyq) : gs == 2 ? fastm_kernel_r<WD, 2>(R, nyq)
-         : gs == 3 ? fastm_kernel_r<WD, 3>(R, nyq) : fastm_kernel_r<WD, 4>(R, nyq);
-}
-#endif // BIOEM_SLIM
-fast_kernel_t fastm_kernel(int winD, int R, bool nyq, int gs)
-{
-#ifdef BIOEM_SLIM
-#ifdef BIOEM_SLIM_FASTM
-  return k_compare_fastm<BIOEM_SLIM_FASTM>;
-#else
-  return nullptr;
-#endif
-#else
-  return winD == 13 ? fastm_kernel_g<13>(R, nyq, gs) : fastm_kernel_g<15>(R, nyq, gs);
-#endif
-}
-
-#ifndef BIOEM_SLIM
-template <int WD>
-fast_kernel_t rows_kernel_g(int gs)
-{
-  return gs == 1 ? k_compare_rows<WD, 1> : gs == 2 ? k_compare_rows<WD, 2> : gs == 3 ? k_compare_rows<WD, 3>
-                                                                                      : k_compare_rows<WD, 4>;
-}
-template <int WD>
-fast_kernel_t oddfft_kernel_r(int R)
-{
-  return R == 25 ? k_compare_oddfft<WD, 25> : R == 15 ? k_compare_oddfft<WD, 15> : R == 9 ? k_compare_oddfft<WD, 9>
-         : R == 5 ? k_compare_oddfft<WD, 5> : k_compare_oddfft<WD, 3>;
-}
-#endif // BIOEM_SLIM
-// odd N: register FFT of odd length R over the reference layout if R > 0 (unit row stride), else direct column sums
-fast_kernel_t rows_kernel(int winD, int gs, int oddR = 0)
-{
-#ifdef BIOEM_SLIM
-  return nullptr;
-#else
-  if (oddR)
-    return winD == 5 ? oddfft_kernel_r<5>(oddR) : winD == 10 ? oddfft_kernel_r<10>(oddR)
-           : winD == 13 ? oddfft_kernel_r<13>(oddR) : oddfft_kernel_r<15>(oddR);
-  return winD == 5 ? rows_kernel_g<5>(gs) : winD == 10 ? rows_kernel_g<10>(gs) : winD == 13 ? rows_kernel_g<13>(gs)
-                                                                                             : rows_kernel_g<15>(gs);
-#endif
-}
-
-fast_kernel_t fast_kernel(int winD, int R, bool nyq, int gs)
-{
-#ifdef BIOEM_SLIM
-  // experiment builds (scripts/slim_build.sh, never shipped): only the instantiations named on the command line are
-  // compiled -- seconds instead of minutes; a shape that selects anything else gets a null kernel and fails the launch
-#ifdef BIOEM_SLIM_FAST
-  return k_compare_fast<BIOEM_SLIM_FAST>;
-#else
-  return nullptr;
-#endif
-#else
-  // (27- and 31-row windows run k_compare_fastm)
-  return winD == 5 ? fast_kernel_g<5>(R, nyq, gs) : fast_kernel_g<10>(R, nyq, gs);
-#endif
-}
-
 // ids == nullptr: row oc of the launch is (orient0 + oc / convPerOrient, conv0 + oc % convPerOrient) (native path);
 // otherwise ids[oc] = {orientation, CTF} and segs[0..nSeg) = runs of equal orientation (compat ring)
 int launch_compare_fold(bioem_hip_ctx *h, const BatchBuf &bb, int nOC, int orient0, int conv0, int convPerOrient,
@@ -632,8 +317,7 @@ int launch_compare_fold(bioem_hip_ctx *h, const BatchBuf &bb, int nOC, int orien
   a.pchunk = h->pchunk > 0 ? std::min(h->pchunk, h->nMaps) : h->nMaps;
   const int ocGroups = (nOC + 3) / 4;
   // few particles: whole groups per XCD (fast_block_pair); the grid is padded to a multiple of 8 groups
-  const bool groupPerXcd = h->nMaps <= 64 && h->fast && !h->wide2 && !(h->tileT && h->wideWPC) &&
-                           !getenv("BIOEM_NO_GROUP_XCD");
+  const bool groupPerXcd = h->nMaps <= 64 && h->fast && !h->wide2 && !getenv("BIOEM_NO_GROUP_XCD");
   if (groupPerXcd)
     a.pchunk = -1;
   const dim3 grid((unsigned) ((size_t) (groupPerXcd ? (ocGroups + 7) / 8 * 8 : ocGroups) * h->nMaps));
@@ -666,23 +350,13 @@ int launch_compare_fold(bioem_hip_ctx *h, const BatchBuf &bb, int nOC, int orien
       else
         hipLaunchKernelGGL(k_nyquist_rows<42>, gridq, dim3(256), 0, h->stream, aw);
     }
-    const size_t lds = wide2_lds_bytes(h->N, 2 * h->fast, h->w2Rows2, h->w2TS, h->w2NW);
-    hipLaunchKernelGGL(wide2_pick(2 * h->fast, h->w2NRW, h->w2NBLK, h->nyq, h->w2Halves, h->w2NW),
-                       dim3((unsigned) ((size_t) nOC * h->nMaps)), dim3(64 * h->w2NW), lds, h->stream, aw);
+    hipLaunchKernelGGL(reinterpret_cast<fast_kernel_t>(const_cast<void *>(h->fn)), dim3((unsigned) ((size_t) nOC * h->nMaps)), dim3(64 * h->w2NW), h->ldsBytes, h->stream, aw);
   }
   else if (h->fast || h->rowsK)
   {
-    const int NW = 2 * h->winD + 1;
-    const size_t lds = h->fastm ? fastm_lds_bytes(h->N)
-                                : fast_lds_bytes(h->N, NW, 4, h->fast ? fast_half_t(h->winD, 2 * h->fast) : false);
     auto launch_window = [&](const CompareArgs &aw) {
-      if (h->rowsK)
-      {
-        hipLaunchKernelGGL(rows_kernel(h->winD, h->gs, h->oddR), grid, dim3(256), lds, h->stream, aw);
-        return;
-      }
       if (h->nyq)
-      {
+      { // Nyquist column of the 64-column blocks (N / 2 a multiple of 64): its window rows by direct summation
         const dim3 gridq((unsigned) (((size_t) (h->nMaps + 15) / 16) * ((nOC + 15) / 16)));
         if (h->winD == 5)
           hipLaunchKernelGGL(k_nyquist_rows<5>, gridq, dim3(256), 0, h->stream, aw);
@@ -693,9 +367,7 @@ int launch_compare_fold(bioem_hip_ctx *h, const BatchBuf &bb, int nOC, int orien
         else
           hipLaunchKernelGGL(k_nyquist_rows<15>, gridq, dim3(256), 0, h->stream, aw);
       }
-      hipLaunchKernelGGL(h->fastm ? fastm_kernel(h->winD, 2 * h->fast, h->nyq, h->gs)
-                                  : fast_kernel(h->winD, 2 * h->fast, h->nyq, h->gs),
-                         grid, dim3(256), lds, h->stream, aw);
+      hipLaunchKernelGGL(reinterpret_cast<fast_kernel_t>(const_cast<void *>(h->fn)), grid, dim3(256), h->ldsBytes, h->stream, aw);
     };
     if (!h->tileT)
       launch_window(a);
@@ -708,41 +380,6 @@ int launch_compare_fold(bioem_hip_ctx *h, const BatchBuf &bb, int nOC, int orien
       at.disp = h->dDispLocal;
       at.nd = h->tileT;
       at.maxD = h->winD * h->gs;
-      if (h->wideWPC)
-      { // per x-tile: conv shifted in x only, then all y-tiles in groups of wideWPC inside k_compare_wide
-        const int wpc = h->wideWPC, cpb = 4 / wpc;
-        const dim3 gridw((unsigned) ((size_t) ((nOC + cpb - 1) / cpb) * h->nMaps));
-        const size_t ldsw = wide_lds_bytes(h->N, h->H, wpc, h->nyq);
-        at.nTiles = nT;
-        at.tileCenter = h->dTileCenter;
-        at.tileValid = h->dTileValid;
-        at.tileStride = tileStride;
-        for (int tx = 0; tx < nT; tx++)
-        {
-          const int sx = h->gs * h->tileCenter[tx];
-          if (sx == 0)
-            at.conv = bb.conv;
-          else
-          {
-            hipLaunchKernelGGL(k_phase_shift, dim3(2048), dim3(256), 0, h->stream, bb.conv, h->dConvShift, total, h->N,
-                               h->H, h->fast, h->N1, sx, 0, h->dTw);
-            at.conv = h->dConvShift;
-          }
-          at.ndx = h->tileValid[tx];
-          at.partials = h->dPartTiles + (size_t) (tx * nT) * tileStride;
-          if (h->nyq)
-          { // Nyquist-column rows of this x-tile (they do not depend on the y-tile)
-            const dim3 gridq((unsigned) (((size_t) (h->nMaps + 15) / 16) * ((nOC + 15) / 16)));
-            hipLaunchKernelGGL(k_nyquist_rows<10>, gridq, dim3(256), 0, h->stream, at);
-          }
-          for (int y0 = 0; y0 < nT; y0 += wpc)
-          {
-            at.yTile0 = y0;
-            hipLaunchKernelGGL(wide_kernel(2 * h->fast, h->gs, wpc, h->nyq), gridw, dim3(256), ldsw, h->stream, at);
-          }
-        }
-      }
-      else
       for (int tx = 0; tx < nT; tx++)
         for (int ty = 0; ty < nT; ty++)
         {
@@ -769,9 +406,8 @@ int launch_compare_fold(bioem_hip_ctx *h, const BatchBuf &bb, int nOC, int orien
   else
   {
     const int gw = h->genericWaves;
-    const size_t lds = compare_lds_bytes(h->N, h->H, h->nd, gw);
     const dim3 gridg((unsigned) ((size_t) ((nOC + gw - 1) / gw) * h->nMaps));
-    hipLaunchKernelGGL(k_compare_generic, gridg, dim3(64 * gw), lds, h->stream, a);
+    hipLaunchKernelGGL(reinterpret_cast<fast_kernel_t>(const_cast<void *>(h->fn)), gridg, dim3(64 * gw), h->ldsBytes, h->stream, a);
   }
   HIP_CHECK(h, hipGetLastError());
   HIP_CHECK(h, hipEventRecord(e1, h->stream));
@@ -1030,392 +666,45 @@ static int create_impl(bioem_hip_handle *out, int device, const bioem_hip_param_
     HIP_CHECK(h, hipStreamCreateWithPriority(&h->stream, hipStreamNonBlocking, prHigh));
   }
 
-  // displacement list per axis in the reference's visiting order
-  const int maxD = pd->maxDisplaceCenter, g = pd->GridSpaceCenter;
-  if (algo == 1)
-  { // bioem_algorithm.h:156-197
-    for (int c = 0; c <= maxD; c += g)
-      h->disp.push_back(c);
-    for (int c = N - maxD; c < N; c += g)
-      h->disp.push_back(c - N);
-  }
-  else
-  { // bioem.cpp:1477-1485
-    const int NxDisp = 2 * (maxD / g) + 1;
-    for (int m = 0; m < NxDisp; m++)
-      h->disp.push_back(m * g - maxD);
-  }
-  h->nd = (int) h->disp.size();
-
-  // fast path: N = N1 * R, R = register-FFT length; h->fast holds R/2 (rows per k1 step)
-  // window rows: row m holds displacement m * gs, gs = gcd of all offsets (1..4 are instantiated), so a coarse grid
-  // with maxD a multiple of the spacing reaches +-15*gs pixels
+  // which kernel runs this shape: kernel_select.hpp (pure function of N and the displacement set)
+  const int maxD = pd->maxDisplaceCenter;
   {
-    int gg = 0;
-    for (int d : h->disp)
+    KernelPlan P = plan_kernels(N, maxD, pd->GridSpaceCenter, algo);
+    if (P.err || !P.fn)
     {
-      int x = d < 0 ? -d : d, y = gg;
-      while (y)
-      {
-        const int t = x % y;
-        x = y;
-        y = t;
-      }
-      gg = x;
-    }
-    h->gs = (gg >= 1 && gg <= 4) ? gg : 1;
-  }
-  // window template: 2*winD+1 rows, nd <= rows (ALGO 1 with maxD % grid != 0 visits up to 2*(maxD/grid)+2 offsets)
-  const int mD = maxD / h->gs;
-  h->winD = (mD <= 5 && h->nd <= 11) ? 5 : (mD <= 10 && h->nd <= 21) ? 10 : (mD <= 13 && h->nd <= 27) ? 13 : 15;
-  // wide windows: more rows than the 31-row template -> tiles of 21 or 31 rows (window_tiles.hpp); needs the plain
-  // symmetric set {gs*m, |m| <= mD}
-  h->tileT = 0;
-  h->tilesPerAxis = 1;
-  // wide windows, first choice: k_compare_wide2 (one launch per batch, shared column transforms, row FFT).  Needs an
-  // even image size with at most two 64-column blocks, at most 32 (one block) / 21 (two blocks) window rows per wave,
-  // and its T block [rows][H] in LDS
-  // ... and for the 23..31-row windows where the 27/31-row templates of k_compare_fast are weak: the sizes that keep
-  // 32-point FFTs there (Nyquist split: 128^2 +-15 px 47.7 -> 54.8 M/s, 256^2 20.8 -> 24.0) and images whose second
-  // column block is mostly empty (160^2 +-15 px 36.1 -> 43.9, 192^2 33.8 -> 38.1); at 200^2 / 224^2 / 240^2 the two tie
-  // (31.5 / 33.6 / 29.8 vs 29.8 / 32.6 / 29.7) and at 96^2 the template wins (73.1 vs 67.8): those keep it
-  const bool nyqSize0 = BIOEM_NYQUIST_SPLIT && N % 2 == 0 && (N / 2) % 64 == 0;
-  // (k_compare_fastm took these windows over; BIOEM_MID_WIDE2 brings the old choice back for A/B runs)
-  const bool midWindow = h->nd > 21 && h->nd <= 31 && (nyqSize0 || (h->H > 64 && h->H <= 100)) &&
-                         getenv("BIOEM_MID_WIDE2");
-  if (N % 2 == 0 && N >= 8 && (mD > 15 || h->nd > 31 || midWindow || (getenv("BIOEM_FORCE_WIDE2") && h->nd >= 21)) &&
-      h->nd == 2 * mD + 1 && !getenv("BIOEM_NO_WIDE2"))
-  {
-    int R = (N % 32 == 0) ? 32 : (N % 16 == 0) ? 16 : (N % 8 == 0) ? 8 : (N % 4 == 0) ? 4 : 2;
-    if (R < 8 && !getenv("BIOEM_POW2_FFT"))
-    {
-      static const int mixed[] = {30, 20, 18, 12, 10, 6};
-      for (int r : mixed)
-        if (N % r == 0 && r > R)
-        {
-          R = r;
-          break;
-        }
-    }
-    if (const char *fr = getenv("BIOEM_W2_R"))
-    { // experiments: a given register-FFT length where it divides N
-      const int r = atoi(fr);
-      static const int lens[] = {32, 16, 8, 4, 2, 30, 20, 18, 12, 10, 6};
-      for (int l : lens)
-        if (l == r && N % r == 0)
-          R = r;
-    }
-    const bool nyq = BIOEM_NYQUIST_SPLIT && (N / 2) % 64 == 0;
-    const int nblk = nyq ? (h->H - 1) / 64 : (h->H + 63) / 64;
-    const int rpw = (h->nd + 3) / 4;
-    // the longest length with a three-waves-per-SIMD instantiation (16, 12, 10, 8) that divides N
-    int r3 = 0;
-    if (!getenv("BIOEM_W2_R"))
-    {
-      static const int lens3[] = {16, 12, 10, 8};
-      for (int l : lens3)
-        if (!r3 && N % l == 0 && (l == 16 || !nyq))
-          r3 = l;
-    }
-    else if (R == 16 || ((R == 12 || R == 10 || R == 8) && !nyq))
-      r3 = R;
-    const bool mixedLen = R != 32 && R != 16 && R != 8 && R != 4 && R != 2;
-    const int rows2 = 2 * ((h->nd + 1) / 2);
-    int ts = h->H; // row stride = 4 mod 16 float2: the (row pair, k1) lanes of the row pass spread over the banks
-    while (ts % 16 != 4)
-      ts++;
-    // small variant (see wide2_kernel_small): measured at 224^2 against the tiled kernel / the 31-row template / the
-    // two-wave instantiation: +-20 px 24.3 vs 20.7 M/s, +-24 px 22.7 vs 17.7, +-15 px 32.8 vs 31.7, +-12 px 33.5 vs 34.6
-    // -> used from 32 rows on
-    // (three blocks per CU must fit: at 256^2 the 13-row variant does not -- +-24 px 11.8 vs 14.9 M/s for the two-wave
-    // instantiation -- the 11-row one does: +-16 px 17.4 -> 23.2, +-20 px 17.4 -> 17.7)
-    // Mixed-radix sizes take it with a 12- or 10-point FFT (`scripts/w2_length_sweep.sh`: 180^2 +-20 px 21.0 on the
-    // tiled kernel -> 29.5, 150^2 25.9 -> 32.4, 200^2 19.9 with 8 points -> 22.3 with 10)
-    const bool small = nblk == 2 && rpw <= 13 && r3 && wide2_lds_bytes(N, r3, rows2, ts) <= 160 * 1024 / 3 &&
-                       !getenv("BIOEM_NO_WIDE2_SMALL");
-    // the same for one column block (measured: 128^2 +-40 px 21.1 -> 23.3, +-30 px 27.8 -> 38.6, 120^2 +-25 px 29.2 -> 38.6;
-    // 90^2 +-30 px 30.2 with 30 points at two waves -> 43.1 with 10, 120^2 +-30 px 34.9 with 8 -> 39.1 with 12)
-    const bool small1 = nblk == 1 && rpw <= 21 && r3 && !getenv("BIOEM_NO_WIDE2_SMALL");
-    if (small || small1)
-      R = r3;
-    // two column blocks of up to 21 rows per wave: with 16-point FFTs the kernel needs 146 registers (three waves per
-    // SIMD) and half the slot space -- worth it exactly where three blocks per CU then fit (224^2 +-26 px: 17.6 -> 18.7
-    // M/s; one row more and only two fit: 14.3)
-    if (R == 32 && nblk == 2 && !small && wide2_lds_bytes(N, 16, rows2, ts) <= 160 * 1024 / 3 &&
-        !getenv("BIOEM_NO_WIDE2_SMALL"))
-      R = 16;
-    // sizes whose power-of-two part is 8 (200, 120, 280): the two-wave instantiations run faster on the longest
-    // mixed length (200^2 +-30 px 11.2 -> 15.3 M/s, +-40 px 9.2 -> 12.7 with 20 points)
-    if (R == 8 && !small && !small1 && !getenv("BIOEM_W2_R") && !getenv("BIOEM_POW2_FFT"))
-    {
-      static const int mixed[] = {30, 20, 18, 12, 10};
-      for (int r : mixed)
-        if (N % r == 0)
-        {
-          R = r;
-          break;
-        }
-    }
-    // measured against the tiled k_compare_wide (224^2): +-20 px (two 21-row tiles per axis) 15.9 vs 20.7 M/s, +-30 px
-    // (three tiles) 14.8 vs 9.6, +-40 px 12.5 vs 7.2; with a T block beyond 80 KiB only one block fits a CU (256^2
-    // +-40 px: 5.5 vs 6.2) -> this kernel from three tiles per axis on, while two blocks per CU fit
-    // a T block that leaves one block per CU goes through LDS in two halves of the window rows where that brings the
-    // second block back (k_compare_wide2<.., HALVES = 2>: 256^2 +-40 px 6.1 on the tiled kernel, 6.7 at one block per CU,
-    // 11.1 in halves).  Halves + 16-point FFTs for a THIRD block per CU at 224^2 lose: +-40 px 12.1 vs 13.9, +-30 px 14.8 vs 17.1
-    const int hrows = (rows2 / 2 + 1) & ~1;
-    // three column blocks (256 < N <= 384): 63 rows of T accumulators per wave at two waves per SIMD, against the tiled
-    // kernel 320^2 +-30 px 5.5 -> 7.4 M/s, +-40 px 4.1 -> 6.8, 288^2 +-30 px 6.0 -> 9.4, 272^2 +-40 px 4.8 -> 7.2, 384^2 +-40 px
-    // 3.1 -> 5.7; from 32 window rows on (320^2 +-20 px 7.8 -> 9.7, 288^2 8.6 -> 10.0, 300^2 7.8 -> 9.7)
-    const bool blocks3 = nblk == 3 && (R == 32 || ((R == 16 || R == 8 || R == 30 || R == 20 || R == 12 || R == 10) && !nyq)) &&
-                         !getenv("BIOEM_NO_WIDE2_BLOCKS3");
-    const bool blocks4 = nblk == 4 && (R == 32 || (R == 16 && !nyq)) && rpw <= 11 && h->nd > 31 &&
-                         !getenv("BIOEM_NO_WIDE2_BLOCKS4");
-    const bool halves2 = (nblk == 2 || blocks3 || blocks4) && !small && wide2_lds_bytes(N, R, rows2, ts) > 80 * 1024 &&
-                         wide2_lds_bytes(N, R, hrows, ts) <= 80 * 1024 && !getenv("BIOEM_NO_WIDE2_HALVES");
-    const int N1 = N / R;
-    const int ldsRows = halves2 ? hrows : rows2;
-    const bool pays = ((h->nd > 42 || ((blocks3 || blocks4) && h->nd > 31) || ((small || small1) && (h->nd > 31 || (midWindow && !mixedLen)))) &&
-                       wide2_lds_bytes(N, R, ldsRows, ts) <= 80 * 1024) ||
-                      getenv("BIOEM_FORCE_WIDE2");
-    const bool rows24 = nblk == 2 && (R == 32 || (R == 16 && !nyq)) && rpw > 21 && rpw <= 24; // 208^2 +-42 px: 3.2 M/s tiled
-    if (pays && (nblk <= 2 || blocks3 || blocks4) && rpw <= (nblk == 1 ? 32 : rows24 ? 24 : 21) && N1 <= 32 && h->nd <= 128 &&
-        (!nyq || mD <= 42) &&
-        wide2_lds_bytes(N, R, ldsRows, ts) <= 160 * 1024)
-    {
-      h->w2Halves = halves2 ? 2 : 1;
-      h->wide2 = true;
-      h->fast = R / 2;
-      h->N1 = N1;
-      h->nyq = nyq;
-      h->w2NBLK = nblk;
-      h->w2NRW = nblk == 1 ? 32 : rows24 ? 24 : blocks4 ? 11 : 21;
-      if (small)
-        h->w2NRW = rpw <= 11 ? 11 : 13;
-      if (small1)
-        h->w2NRW = 21;
-      h->w2TS = ts;
-      h->w2Rows2 = ldsRows; // rows of the T block in LDS
-      h->nyqWD = mD <= 20 ? 20 : mD <= 31 ? 31 : 42;
-      if (nyq)
-        h->winD = h->nyqWD; // sizes the Nyquist pre-kernel's tables
-      int ldsFinal = (int) wide2_lds_bytes(N, R, ldsRows, ts);
-      // eight waves per comparison (512-thread blocks, `k_compare_wide2<.., NW = 8>`): 11 rows per wave over two column
-      // blocks with a 16- / 12- / 10- / 8-point FFT -- 110 registers, four waves per SIMD at two blocks per CU.  It wins
-      // where the four-wave kernel of that length is held to two blocks per CU by its T block (208^2 +-30 px 14.5 ->
-      // 17.7 M/s, +-40 px 11.8 -> 14.1, 240^2 +-30 px 13.4 -> 16.0, 176^2 +-40 px 13.4 -> 15.2, 144^2 +-40 px 14.7 -> 17.4) and
-      // loses against three blocks per CU (176^2 +-30 px 22.9 vs 19.1), against the 32-point two-wave kernel (224^2 +-40 px
-      // 13.8 vs 13.4) and with the T block in halves (240^2 +-40 px 11.8 vs 9.5: spills under the 128-register cap)
-      {
-        int r8 = 0;
-        if (const char *f8 = getenv("BIOEM_W2_W8"))
-          r8 = atoi(f8); // experiments: force a length (16, 12, 10, 8)
-        else if ((R == 16 || R == 10) && !nyq && !getenv("BIOEM_NO_WIDE2_W8"))
-          r8 = R; // (250^2 +-30 px 10.2 -> 12.1 with 10 points; 200^2 keeps its 20-point two-wave kernel: 15.3 vs 14.4)
-        const bool ok8 = (r8 == 16 || ((r8 == 12 || r8 == 10 || r8 == 8) && !nyq)) && N % r8 == 0 && N / r8 <= 32;
-        if (ok8 && nblk == 2 && !small && h->w2Halves == 1 && (h->nd + 7) / 8 <= 11 &&
-            wide2_lds_bytes(N, r8, rows2, ts, 4) > 160 * 1024 / 3 && wide2_lds_bytes(N, r8, rows2, ts, 8) <= 80 * 1024)
-        {
-          R = r8;
-          h->w2NW = 8;
-          h->fast = r8 / 2;
-          h->N1 = N / r8;
-          h->w2NRW = 11;
-          h->w2Rows2 = rows2;
-          ldsFinal = (int) wide2_lds_bytes(N, r8, rows2, ts, 8);
-        }
-      }
-      HIP_CHECK(h, hipFuncSetAttribute(reinterpret_cast<const void *>(
-                                           wide2_pick(R, h->w2NRW, nblk, nyq, h->w2Halves, h->w2NW)),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, ldsFinal));
-    }
-  }
-  // four column blocks with 45..88 window rows: eight waves per comparison, one 512-thread block per CU (T block whole
-  // or in halves within 160 KiB) -- the tiled kernel runs 512^2 +-40 px at 1.7 M/s
-  if (!h->wide2 && N % 2 == 0 && h->nd == 2 * mD + 1 && h->nd > 44 && (h->nd + 7) / 8 <= 11 && !getenv("BIOEM_NO_WIDE2") &&
-      !getenv("BIOEM_NO_WIDE2_BLOCKS4"))
-  {
-    const bool nyq = BIOEM_NYQUIST_SPLIT && (N / 2) % 64 == 0;
-    const int nblk = nyq ? (h->H - 1) / 64 : (h->H + 63) / 64;
-    const int R = (N % 32 == 0) ? 32 : (N % 16 == 0 && !nyq) ? 16 : 0;
-    const int rows2 = 2 * ((h->nd + 1) / 2), hrows = (rows2 / 2 + 1) & ~1;
-    int ts = h->H;
-    while (ts % 16 != 4)
-      ts++;
-    // (measured: 512^2 +-40 px 1.67 -> 2.28 M/s, +-30 px 2.11 -> 2.96, 448^2 +-40 px 2.48 -> 3.71; with 16 points 400^2 +-40 px
-    // 2.80 -> 3.11 but +-30 px 3.74 -> 3.42: from 71 rows on there)
-    if (nblk == 4 && R && (R == 32 || h->nd > 70) && N / R <= 32 && (!nyq || mD <= 42))
-    {
-      const bool full = wide2_lds_bytes(N, R, rows2, ts, 8) <= 160 * 1024;
-      const bool half = !full && wide2_lds_bytes(N, R, hrows, ts, 8) <= 160 * 1024;
-      if (full || half)
-      {
-        h->wide2 = true;
-        h->w2NW = 8;
-        h->w2Halves = half ? 2 : 1;
-        h->fast = R / 2;
-        h->N1 = N / R;
-        h->nyq = nyq;
-        h->w2NBLK = 4;
-        h->w2NRW = 11;
-        h->w2TS = ts;
-        h->w2Rows2 = half ? hrows : rows2;
-        h->nyqWD = mD <= 20 ? 20 : mD <= 31 ? 31 : 42;
-        if (nyq)
-          h->winD = h->nyqWD;
-        HIP_CHECK(h, hipFuncSetAttribute(reinterpret_cast<const void *>(wide2_pick(R, 11, 4, nyq, h->w2Halves, 8)),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize,
-                                         (int) wide2_lds_bytes(N, R, h->w2Rows2, ts, 8)));
-      }
-    }
-  }
-  if (!h->wide2 && N >= 8 && (mD > 15 || h->nd > 31) && h->nd == 2 * mD + 1 && !getenv("BIOEM_NO_TILES"))
-  {
-    const int W = h->nd;
-    // launches^2 x the measured cost of one launch of the 21- / 27- / 31-row kernel (ms at 224^2)
-    static const int tileRows[3] = {21, 27, 31};
-    static const double tileCost[3] = {6.5, 9.25, 9.9};
-    double best = 1e300;
-    for (int k = 0; k < 3; k++)
-    {
-      const int nt = (W + tileRows[k] - 1) / tileRows[k];
-      if (nt * nt * tileCost[k] < best)
-      {
-        best = nt * nt * tileCost[k];
-        h->tileT = tileRows[k];
-      }
-    }
-    if (getenv("BIOEM_TILE_ROWS"))
-    {
-      const int t = atoi(getenv("BIOEM_TILE_ROWS"));
-      h->tileT = (t == 31 || t == 27) ? t : 21;
-    }
-    // k_compare_wide shares the column transforms between the y-tiles of an x-tile: 21-row tiles, power-of-two
-    // at most four 64-column blocks
-    const bool nyqSize = BIOEM_NYQUIST_SPLIT && (N / 2) % 64 == 0; // Nyquist column outside the 64-column blocks
-    const int wideBlocks = nyqSize ? (h->H - 1) / 64 : (h->H + 63) / 64;
-    if (N % 2 == 0 && wideBlocks <= 4 && h->gs <= 2 && !getenv("BIOEM_NO_WIDE") && !getenv("BIOEM_TILE_ROWS"))
-    {
-      h->tileT = 21;
-      // waves per comparison: one per y-tile, and at least one per column block
-      h->wideWPC = ((W + 20) / 21 == 2 && wideBlocks <= 2) ? 2 : 4;
-    }
-    h->tilesPerAxis = (W + h->tileT - 1) / h->tileT;
-    h->winD = (h->tileT - 1) / 2;
-    for (int k = 0; k < h->tilesPerAxis; k++)
-    {
-      h->tileCenter.push_back(-mD + k * h->tileT + h->winD);               // centre row of tile k
-      h->tileValid.push_back(std::min(h->tileT, W - k * h->tileT));        // rows of tile k inside the window
-    }
-  }
-  if (!h->wide2)
-    h->fast = 0;
-  if (!h->wide2 && N % 2 == 0 && N >= 8 && ((maxD / h->gs <= 15 && h->nd <= 31) || h->tileT))
-  {
-    int R = (N % 32 == 0) ? 32 : (N % 16 == 0) ? 16 : (N % 8 == 0) ? 8 : (N % 4 == 0) ? 4 : 2;
-    // 31-row window: a 16-point register FFT keeps the kernel at 3 waves per SIMD (see fast_half_t); sizes that
-    // take the Nyquist split (N/2 a multiple of 64) keep R = 32
-    if (h->winD > 10 && R == 32 && fast_half_t(15, 16) && (N / 2) % 64 != 0 && !getenv("BIOEM_WIDE_R32"))
-      R = 16;
-    if (R < 8 && h->gs == 1 && !getenv("BIOEM_POW2_FFT"))
-    { // power-of-two part 2 or 4: the largest 2/3/5-smooth even divisor <= 30 (mixed-radix register FFT) wins
-      // (measured: 250^2 20 -> 40 M/s, 180^2 47 -> 53, 100^2 129 -> 143; with a part of 8 it does not: 200^2, 120^2)
-      // 27/31-row windows: lengths up to 16 keep three waves per SIMD (fast_half_t), as for the powers of two
-      static const int mixed[] = {30, 20, 18, 12, 10, 6};
-      const bool small16 = h->winD > 10 && fast_half_t(15, 16) && !getenv("BIOEM_WIDE_R32");
-      for (int r : mixed)
-        if (N % r == 0 && r > R && !(small16 && r > 16))
-        {
-          R = r;
-          break;
-        }
-    }
-    h->fast = R / 2;
-  }
-  if (!h->wide2)
-  {
-    h->N1 = h->fast ? N / (2 * h->fast) : 0;
-    h->nyq = BIOEM_NYQUIST_SPLIT && h->fast && (N / 2) % 64 == 0;
-    // 11-row windows: with four column blocks and a length <= 16 (or 40+ column steps) the 21-row template is the faster
-    // one (+-5 px: 432^2 11.0 -> 13.0 M/s, 360^2 16.7 -> 19.2, 400^2 13.5 -> 14.7; with 32 points 448^2 / 512^2 tie; up to
-    // 336^2 and at 384^2 the 11-row template wins by 7-25 %)
-    const int nblkF = h->nyq ? (h->H - 1) / 64 : (h->H + 63) / 64;
-    if (h->fast && h->winD == 5 && !h->tileT && ((nblkF >= 4 && h->fast <= 8) || h->N1 >= 40) && !getenv("BIOEM_KEEP_WD5"))
-      h->winD = 10;
-  }
-  // 23..31-row windows on even sizes: k_compare_fastm -- window pass on the matrix cores, register FFT of at most 16
-  // points (27/31 rows of T accumulators + a longer FFT do not fit three waves per SIMD)
-  if (!h->wide2 && h->fast && (h->winD > 10 || getenv("BIOEM_FASTM_ALL")) && !(h->tileT && h->wideWPC))
-  {
-    int R = 2 * h->fast;
-    if (R > 16 && !getenv("BIOEM_FASTM_R32"))
-    {
-      static const int lens[] = {16, 12, 10, 8, 6, 4, 2};
-      for (int l : lens)
-        if (N % l == 0 && (h->gs == 1 || (l & (l - 1)) == 0))
-        {
-          R = l;
-          break;
-        }
-    }
-    if (h->nyq && !getenv("BIOEM_FASTM_R32"))
-      R = 16; // (N / 2 a multiple of 64)
-    h->fast = R / 2;
-    h->N1 = N / R;
-    h->fastm = true;
-  }
-  // no even factor (odd N) but a window of at most 31 rows: k_compare_rows (reference layout, direct column sums,
-  // the fast kernel's T exchange / window / posterior) instead of the generic kernel
-  h->rowsK = !h->fast && N >= 8 && (h->tileT || (mD <= 15 && h->nd <= 31)) && !getenv("BIOEM_NO_ROWS_KERNEL");
-  if (h->rowsK && h->gs == 1 && !getenv("BIOEM_NO_ODD_FFT"))
-  {
-    static const int oddLens[] = {25, 15, 9, 5, 3};
-    for (int r : oddLens)
-      if (N % r == 0)
-      {
-        h->oddR = r;
-        h->N1 = N / r;
-        break;
-      }
-  }
-  if (h->tileT && !h->fast && !h->rowsK)
-  { // no tiled kernel available after all: plain generic kernel on the whole window
-    h->tileT = 0;
-    h->tilesPerAxis = 1;
-    h->wideWPC = 0;
-  }
-  // LDS budget check
-  if (!h->wide2)
-  {
-    // generic kernel: as many waves per block (4, 2, 1) as its per-wave T block [nd][H] lets fit
-    h->genericWaves = 4;
-    while (!h->fast && h->genericWaves > 1 && compare_lds_bytes(N, h->H, h->nd, h->genericWaves) > 160 * 1024)
-      h->genericWaves >>= 1;
-    const size_t lds = h->fastm   ? fastm_lds_bytes(N)
-                       : h->fast  ? fast_lds_bytes(N, 2 * h->winD + 1, 4, fast_half_t(h->winD, 2 * h->fast))
-                       : h->rowsK ? fast_lds_bytes(N, 2 * h->winD + 1, 4, false)
-                                  : compare_lds_bytes(N, h->H, h->nd, h->genericWaves);
-    if (lds > 160 * 1024)
-    {
-      h->err = "configuration exceeds the 160 KiB LDS budget of the comparison kernel";
+      h->err = P.err ? P.err : "no comparison kernel for this configuration";
       return 2;
     }
-    if (h->fastm)
-      HIP_CHECK(h, hipFuncSetAttribute(reinterpret_cast<const void *>(fastm_kernel(h->winD, 2 * h->fast, h->nyq, h->gs)),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
-    else if (h->fast)
-      HIP_CHECK(h, hipFuncSetAttribute(reinterpret_cast<const void *>(fast_kernel(h->winD, 2 * h->fast, h->nyq, h->gs)),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
-    else if (h->rowsK)
-      HIP_CHECK(h, hipFuncSetAttribute(reinterpret_cast<const void *>(rows_kernel(h->winD, h->gs, h->oddR)),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int) fast_lds_bytes(N, 2 * h->winD + 1, 4, false)));
-    else
-    {
-      const size_t ldsg = compare_lds_bytes(N, h->H, h->nd, h->genericWaves);
-      HIP_CHECK(h, hipFuncSetAttribute(reinterpret_cast<const void *>(k_compare_generic),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int) ldsg));
-    }
+    h->disp = P.disp;
+    h->nd = P.nd;
+    h->gs = P.gs;
+    h->winD = P.winD;
+    h->family = P.family;
+    h->fast = P.fast;
+    h->N1 = P.N1;
+    h->oddR = P.oddR;
+    h->nyq = P.nyq;
+    h->fastm = P.fastm;
+    h->rowsK = P.rowsK;
+    h->wide2 = P.wide2;
+    h->tileT = P.tileT;
+    h->tilesPerAxis = P.tilesPerAxis;
+    h->tileCenter = P.tileCenter;
+    h->tileValid = P.tileValid;
+    h->w2NRW = P.w2NRW;
+    h->w2NBLK = P.w2NBLK;
+    h->w2TS = P.w2TS;
+    h->w2Rows2 = P.w2Rows2;
+    h->nyqWD = P.nyqWD;
+    h->w2Halves = P.w2Halves;
+    h->w2NW = P.w2NW;
+    h->genericWaves = P.genericWaves;
+    h->fn = reinterpret_cast<const void *>(P.fn);
+    h->ldsBytes = P.ldsBytes;
+    HIP_CHECK(h, hipFuncSetAttribute(h->fn, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     (int) h->ldsBytes));
   }
+  const int mD = maxD / h->gs;
 
   // batch sizing: conv buffer <= ~96 MiB, partial buffer <= ~128 MiB
   const size_t M = (size_t) h->M;
@@ -1495,10 +784,6 @@ static int create_impl(bioem_hip_handle *out, int device, const bioem_hip_param_
     HIP_CHECK(h, hipMemcpy(h->dTileCenter, h->tileCenter.data(), sizeof(int) * nT, hipMemcpyHostToDevice));
     HIP_CHECK(h, hipMalloc(&h->dTileValid, sizeof(int) * nT));
     HIP_CHECK(h, hipMemcpy(h->dTileValid, h->tileValid.data(), sizeof(int) * nT, hipMemcpyHostToDevice));
-    if (h->wideWPC)
-      HIP_CHECK(h, hipFuncSetAttribute(reinterpret_cast<const void *>(wide_kernel(2 * h->fast, h->gs, h->wideWPC, h->nyq)),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int) wide_lds_bytes(N, h->H, h->wideWPC, h->nyq)));
   }
   h->devProbBytes = bioem_hip_prob_size(nMaps, angO1 - angO0, pd->writeAngles);
   h->probBytes = shard ? bioem_hip_prob_size(nMaps, 0, 0) : h->devProbBytes;
@@ -1602,7 +887,7 @@ static int create_impl(bioem_hip_handle *out, int device, const bioem_hip_param_
     {
       fprintf(f, "%s\n", bioem_hip_kernel_signature(h));
       if (h->nyq)
-        fprintf(f, "k_nyquist_rows<%d>\n", h->wide2 ? h->nyqWD : (h->tileT && h->wideWPC) ? 10 : h->winD);
+        fprintf(f, "k_nyquist_rows<%d>\n", h->wide2 ? h->nyqWD : h->winD);
       fclose(f);
     }
   return 0;
@@ -2328,6 +1613,23 @@ int bioem_hip_debug_w2_stamps(unsigned long long *out8)
 
 int bioem_hip_uses_fast_path(bioem_hip_handle h) { return h && h->fast ? 1 : 0; }
 
+int bioem_hip_plan(int numberPixels, int maxDisplaceCenter, int gridSpaceCenter, int algo, char *signature, int cap)
+{
+  if (numberPixels < 2 || numberPixels > kMaxPixels || maxDisplaceCenter < 0 || gridSpaceCenter < 1 ||
+      maxDisplaceCenter >= numberPixels / 2 || !signature || cap < 1)
+    return 2;
+  const KernelPlan P = plan_kernels(numberPixels, maxDisplaceCenter, gridSpaceCenter, algo);
+  if (P.err || !P.fn)
+    return 1;
+  plan_signature(P, signature, (size_t) cap);
+  if (P.tileT)
+  {
+    const size_t n = strlen(signature);
+    snprintf(signature + n, (size_t) cap - n, " x %d^2 tiles of %d rows", P.tilesPerAxis, P.tileT);
+  }
+  return 0;
+}
+
 const char *bioem_hip_kernel_name(bioem_hip_handle h)
 {
   if (!h)
@@ -2337,7 +1639,7 @@ const char *bioem_hip_kernel_name(bioem_hip_handle h)
   if (h->fastm)
     return "k_compare_fastm";
   if (h->fast)
-    return (h->tileT && h->wideWPC) ? "k_compare_wide" : "k_compare_fast";
+    return "k_compare_fast";
   return h->rowsK ? (h->oddR ? "k_compare_oddfft" : "k_compare_rows") : "k_compare_generic";
 }
 
@@ -2354,8 +1656,6 @@ const char *bioem_hip_kernel_signature(bioem_hip_handle h)
     else
       snprintf(buf, sizeof(buf), h->w2NW == 8 ? "k_compare_wide2<%d, %d, %d, %s, 1, 8>" : "k_compare_wide2<%d, %d, %d, %s>",
                2 * h->fast, h->w2NRW, h->w2NBLK, nq);
-  else if (h->fast && h->tileT && h->wideWPC)
-    snprintf(buf, sizeof(buf), "k_compare_wide<%d, %d, %d, %s>", 2 * h->fast, h->gs, h->wideWPC, nq);
   else if (h->fastm)
     snprintf(buf, sizeof(buf), "k_compare_fastm<%d, %d, %s, %d>", h->winD, 2 * h->fast, nq, h->gs);
   else if (h->fast)

@@ -27,11 +27,6 @@ struct CompareArgs
   // window tiles (wide windows are covered by several launches over phase-shifted conv spectra): only the first
   // ndx rows (sorted order) and the first ndy lanes of the displacement list count; nd for an untiled launch
   int ndx, ndy;
-  // k_compare_wide (several y-tiles per launch): first y-tile of the launch, tiles per axis, tile tables (centre in
-  // window rows, rows inside the window), distance between the partial buffers of consecutive tiles
-  int yTile0, nTiles;
-  const int *tileCenter, *tileValid;
-  size_t tileStride;
   // k_compare_wide2: row stride of the LDS T block (float2 units); window half width of the k_nyquist_rows
   // instantiation that filled tnyq (its rows run -nyqWD..nyqWD)
   int ts, nyqWD;

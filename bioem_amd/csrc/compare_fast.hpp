@@ -351,7 +351,8 @@ __global__ __launch_bounds__(256, fast_waves_per_simd(WD, R)) void k_compare_fas
   constexpr int NW = 2 * WD + 1;
   constexpr int R2 = R / 2;            // rows (k2 pairs) per k1 step
   // depth of the operand ring: must divide R2 so that a ring slot is a compile-time function of the k2 pair
-  constexpr int RD = (R2 % 4 == 0) ? 4 : (R2 % 5 == 0) ? 5 : (R2 % 3 == 0) ? 3 : (R2 % 2 == 0) ? 2 : 1;
+  // (R = 30: a ring of 3, not 5 -- 16 registers the 21-row window of that length needs)
+  constexpr int RD = (R2 % 4 == 0) ? 4 : (R2 == 15) ? 3 : (R2 % 5 == 0) ? 5 : (R2 % 3 == 0) ? 3 : (R2 % 2 == 0) ? 2 : 1;
   constexpr int NR = (WD <= 5) ? 3 : (WD <= 10) ? 7 : 16; // accumulators (window rows) per lane
   // T row stride in float2 (64 or 32 columns + 2 pad: row groups land on different banks)
   constexpr int TS = HALF ? 34 : 66;

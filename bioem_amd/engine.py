@@ -83,6 +83,7 @@ def load_library():
     L.bioem_hip_kernel_name.restype = C.c_char_p
     L.bioem_hip_kernel_signature.argtypes = [vp]
     L.bioem_hip_kernel_signature.restype = C.c_char_p
+    L.bioem_hip_plan.argtypes = [ci, ci, ci, ci, C.c_char_p, ci]
     L.bioem_hip_synchronize.argtypes = [vp]
     L.bioem_hip_r2c.argtypes = [ci, ci, ci, vp, vp]
     _lib = L
@@ -98,7 +99,7 @@ EXPORTS = ["bioem_hip_device_count", "bioem_hip_create", "bioem_hip_create_shard
            "bioem_hip_project_convolve_compare", "bioem_hip_finish_run", "bioem_hip_merge_host",
            "bioem_hip_debug_projection", "bioem_hip_debug_convolution", "bioem_hip_debug_particles",
            "bioem_hip_kernel_stats", "bioem_hip_reset_kernel_stats", "bioem_hip_uses_fast_path",
-           "bioem_hip_kernel_name", "bioem_hip_kernel_signature",
+           "bioem_hip_kernel_name", "bioem_hip_kernel_signature", "bioem_hip_plan",
            "bioem_hip_synchronize", "bioem_hip_r2c"]
 
 

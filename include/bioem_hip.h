@@ -201,6 +201,11 @@ const char *bioem_hip_kernel_name(bioem_hip_handle h);
  * "k_compare_fast<10, 32, false, 1>"): lets bench.py tie its live timing to the committed counter profile of exactly
  * this kernel */
 const char *bioem_hip_kernel_signature(bioem_hip_handle h);
+/* Which comparison kernel a configuration would run, without a device (no reference counterpart; the selection is a
+ * pure function of the image size and the displacement set, bioem_amd/csrc/kernel_select.hpp).  Writes the
+ * instantiation -- and " x T^2 tiles of R rows" for a tiled wide window -- into signature[cap]; 0 on success, 1 when no
+ * kernel fits, 2 on invalid arguments. */
+int bioem_hip_plan(int numberPixels, int maxDisplaceCenter, int gridSpaceCenter, int algo, char *signature, int cap);
 int bioem_hip_synchronize(bioem_hip_handle h);
 
 #ifdef __cplusplus

@@ -249,13 +249,16 @@ def test_multiple_mrc_reader_delivers_the_golden_maps(tmp_path):
     assert np.allclose(maps, case["maps"], rtol=0, atol=2e-6)
 
 
-def test_bench_starts_its_own_ranks_without_a_launcher():
+def test_bench_starts_its_own_ranks_without_a_launcher(tmp_path):
     """`python bench.py --gpus 2` with no WORLD_SIZE in the environment: the parent (which never touches a GPU) must
-    start two child ranks with the launcher contract's variables and hand rank 0's exit code through.  Here, without
-    a GPU, both ranks stop at the device check -- which proves they were started as ranks 0 and 1 of a world of 2."""
+    start two child ranks with the launcher contract's variables and hand the failing rank's exit code through.  Here,
+    without a GPU, both ranks stop at the device check -- which proves they were started as ranks 0 and 1 of a world of
+    2; each rank's stderr is kept in its own file (bench_rank<k>.err)."""
     import subprocess
     import sys
+    import time
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    env["BIOEM_BENCH_LOGDIR"] = str(tmp_path)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
                         "--no-cpu-baseline"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
                        timeout=300)
@@ -263,8 +266,11 @@ def test_bench_starts_its_own_ranks_without_a_launcher():
     if torch.cuda.is_available():
         pytest.skip("needs a box without a GPU (the GPU suite runs bench.py itself)")
     assert r.returncode == 2 and r.stdout.strip() == ""
-    assert r.stderr.count("bench.py needs a GPU") == 2          # one line per self-started rank
-    assert "WORLD_SIZE" not in r.stderr                         # no rank saw a world size other than --gpus
+    assert "exited with code 2" in r.stderr and "bench.py needs a GPU" in r.stderr
+    # the rank that failed first wrote the message; the other either wrote it too or was terminated before it got there
+    logs = [open(tmp_path / ("bench_rank%d.err" % k)).read() for k in (0, 1)]
+    assert any("bench.py needs a GPU" in t for t in logs)
+    assert all("WORLD_SIZE" not in t for t in logs)            # no rank saw a world size other than --gpus
 
 
 def test_cpu_share_detection():
