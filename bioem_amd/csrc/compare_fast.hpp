@@ -6,6 +6,27 @@
 namespace
 {
 
+// wave-uniform table reads through the constant address space: always scalar loads (the uniform global loads of this
+// kernel were otherwise emitted as vector loads, one L2 round trip each)
+typedef const float2 __attribute__((address_space(4))) *const_float2_ptr;
+__device__ __forceinline__ const_float2_ptr as_constant(const float2 *p)
+{
+  return (const_float2_ptr) (unsigned long long) p;
+}
+
+// A wave-uniform pointer, provably so for the compiler: the 64-bit address arithmetic behind it (base + index * size)
+// is done on the vector unit, and a buffer descriptor built from a value the compiler keeps in vector registers makes
+// EVERY buffer load a waterfall loop (4 v_readfirstlane + 2 v_cmp + exec juggling per load; found in all
+// k_compare_wide2 instantiations of round 2).  Two v_readfirstlane here put it into scalar registers once.
+template <typename T>
+__device__ __forceinline__ T *uniform_ptr(T *p)
+{
+  const unsigned long long v = (unsigned long long) p;
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned) v);
+  const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned) (v >> 32));
+  return (T *) (((unsigned long long) hi << 32) | lo);
+}
+
 // ------------------------------------------------------------------------------------------------
 // log of a positive float in double precision, cheap: f = m * 2^e, m in [1,2); c ~ 1/m from a 64-entry
 // table, r = m*c - 1 exactly rounded by one fma (|r| <= 2^-7), log f = e ln2 - log c + log1p(r) with a
@@ -405,9 +426,9 @@ __global__ __launch_bounds__(256, fast_waves_per_simd(WD, R)) void k_compare_fas
 #ifndef BIOEM_ABLATE_C
 #define BIOEM_ABLATE_C 0
 #endif
-  const auto rsrcF = __builtin_amdgcn_make_buffer_rsrc(const_cast<float2 *>(a.ref + (size_t) p * M), 0,
+  const auto rsrcF = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(const_cast<float2 *>(a.ref + (size_t) p * M)), 0,
                                                        BIOEM_ABLATE_F ? 0 : (int) (M * sizeof(float2)), 0x00020000);
-  const auto rsrcC = __builtin_amdgcn_make_buffer_rsrc(const_cast<float2 *>(a.conv + (size_t) oc * M), 0,
+  const auto rsrcC = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(const_cast<float2 *>(a.conv + (size_t) oc * M)), 0,
                                                        BIOEM_ABLATE_C ? 0 : (int) (M * sizeof(float2)), 0x00020000);
 
   // window lanes
@@ -566,32 +587,34 @@ __global__ __launch_bounds__(256, fast_waves_per_simd(WD, R)) void k_compare_fas
       acc[r] = fmaf(sg, tq[is_static ? rowbase / TS + r : row_of(r) / TS], acc[r]);
   }
 
-  const bioem_hip_param5 q = a.params[oc];
-  const float sumref = a.sumRef[p], sumsqref = a.sumsqRef[p];
   const double2 pc = a.postc[oc];
-  const double t2 = pc.x, prior = pc.y;
-  const float Np = a.pd.Ntotpi;
-  const double A = (double) (3 - Np) * 0.5;
-  const float nn = (float) (N * N);
+  const PostW pw = post_consts(a.pd.Ntotpi, N, a.params[oc], a.sumRef[p], a.sumsqRef[p], pc.x, pc.y);
   LseF L;
   L.m = -INFINITY;
   L.s = 0.;
   L.id = 0x7fffffff;
   L.val = 0.f;
-#pragma unroll
-  for (int r = 0; r < NR; r++)
   {
-    const int ixs = grp * nr + r; // position in the lane-group order; ix = visiting rank of that displacement
-    if (r < nr && wactive && ixs < a.ndx && iy < a.ndy)
+    // the NR displacements of this lane as one batch (posterior_batch: exact division by N^2 in three instructions,
+    // the log-table reads issued together, one log-sum-exp rescale)
+    constexpr int PB = NR > 8 ? 8 : NR;
+#pragma unroll
+    for (int r0 = 0; r0 < NR; r0 += PB)
     {
-      const int ix = is_static ? dinv[ixs] : ixs;
-      const float cc = acc[r] / nn;
-      // bioem_algorithm.h:32-36, float expression in the reference's order
-      const float firstele = Np * (sumsqref * q.sumsquareC - cc * cc) + 2 * sumref * q.sumC * cc -
-                             sumsqref * q.sumC * q.sumC - sumref * sumref * q.sumsquareC;
-      double lp = A * log_of_float(firstele, ltab) + t2;
-      lp -= prior;
-      lsef_push(L, lp, ix * nd + iy, cc, a.algo);
+      float accv[PB];
+      int idv[PB];
+      bool okv[PB];
+#pragma unroll
+      for (int j = 0; j < PB; j++)
+      {
+        const int r = r0 + j < NR ? r0 + j : NR - 1;
+        const int ixs = grp * nr + r; // position in the lane-group order; ix = visiting rank of that displacement
+        okv[j] = r0 + j < NR && r < nr && wactive && ixs < a.ndx && iy < a.ndy;
+        const int ix = is_static ? dinv[min(ixs, 31)] : ixs;
+        accv[j] = acc[r];
+        idv[j] = ix * nd + iy;
+      }
+      posterior_batch<PB>(L, accv, idv, okv, pw, ltab, a.algo);
     }
   }
   lsef_wave_reduce(L);

@@ -65,9 +65,9 @@ __global__ __launch_bounds__(256, (WD <= 10 ? 3 : 2)) void k_compare_rows(const 
   const bool oc_valid = oc_raw < a.nOC;
   const int oc = oc_valid ? oc_raw : a.nOC - 1;
   const size_t M = (size_t) N * H;
-  const auto rsrcF = __builtin_amdgcn_make_buffer_rsrc(const_cast<float2 *>(a.ref + (size_t) p * M), 0,
+  const auto rsrcF = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(const_cast<float2 *>(a.ref + (size_t) p * M)), 0,
                                                        (int) (M * sizeof(float2)), 0x00020000);
-  const auto rsrcC = __builtin_amdgcn_make_buffer_rsrc(const_cast<float2 *>(a.conv + (size_t) oc * M), 0,
+  const auto rsrcC = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(const_cast<float2 *>(a.conv + (size_t) oc * M)), 0,
                                                        (int) (M * sizeof(float2)), 0x00020000);
 
   // window lanes (as in k_compare_fast)
@@ -271,9 +271,9 @@ __global__ __launch_bounds__(256, (WD <= 10 ? 3 : 2)) void k_compare_oddfft(cons
   const bool oc_valid = oc_raw < a.nOC;
   const int oc = oc_valid ? oc_raw : a.nOC - 1;
   const size_t M = (size_t) N * H;
-  const auto rsrcF = __builtin_amdgcn_make_buffer_rsrc(const_cast<float2 *>(a.ref + (size_t) p * M), 0,
+  const auto rsrcF = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(const_cast<float2 *>(a.ref + (size_t) p * M)), 0,
                                                        (int) (M * sizeof(float2)), 0x00020000);
-  const auto rsrcC = __builtin_amdgcn_make_buffer_rsrc(const_cast<float2 *>(a.conv + (size_t) oc * M), 0,
+  const auto rsrcC = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(const_cast<float2 *>(a.conv + (size_t) oc * M)), 0,
                                                        (int) (M * sizeof(float2)), 0x00020000);
 
   // window lanes (as in k_compare_fast)

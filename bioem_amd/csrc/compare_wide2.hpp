@@ -47,14 +47,6 @@ __device__ unsigned long long g_w2_stamps[16];
 #define W2_STAMP(k)
 #endif
 
-// wave-uniform table reads through the constant address space: always scalar loads (the uniform global loads of this
-// kernel were otherwise emitted as vector loads, one L2 round trip each)
-typedef const float2 __attribute__((address_space(4))) *const_float2_ptr;
-__device__ __forceinline__ const_float2_ptr as_constant(const float2 *p)
-{
-  return (const_float2_ptr) (unsigned long long) p;
-}
-
 // HALVES = 2: the T block goes through LDS in two halves of the window rows (row pass + posterior per half), for the
 // sizes whose whole T block would leave one block per CU (240^2 ... 256^2 at +-35 ... +-42 px)
 // NW = 8: eight waves per comparison (512-thread blocks) -- half the window rows per wave, so that the 16-point
@@ -115,6 +107,10 @@ __global__ __launch_bounds__(64 * NW, HALVES == 2 ? (NW == 8 ? 1 : 2)
     oc = rem / pc;
     p = c * a.pchunk + (rem - oc * pc);
   }
+  // provably wave-uniform (SGPRs): the buffer descriptors built from them must not end up in vector registers -- every
+  // buffer load would then sit in a waterfall loop (4 v_readfirstlane + 2 v_cmp + exec juggling per load)
+  p = __builtin_amdgcn_readfirstlane(p);
+  oc = __builtin_amdgcn_readfirstlane(oc);
   // constants of the comparison's posterior: fetched by wave 0 while the tables load (read where the posterior
   // starts, their L2 round trips were exposed in all four waves)
   if (wave == 0)
@@ -138,9 +134,9 @@ __global__ __launch_bounds__(64 * NW, HALVES == 2 ? (NW == 8 ? 1 : 2)
 #ifndef BIOEM_W2_ABLATE
 #define BIOEM_W2_ABLATE 0
 #endif
-  const auto rsrcF = __builtin_amdgcn_make_buffer_rsrc(const_cast<float2 *>(a.ref + (size_t) p * M), 0,
+  const auto rsrcF = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(const_cast<float2 *>(a.ref + (size_t) p * M)), 0,
                                                        BIOEM_W2_ABLATE ? 0 : (int) (M * sizeof(float2)), 0x00020000);
-  const auto rsrcC = __builtin_amdgcn_make_buffer_rsrc(const_cast<float2 *>(a.conv + (size_t) oc * M), 0,
+  const auto rsrcC = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(const_cast<float2 *>(a.conv + (size_t) oc * M)), 0,
                                                        BIOEM_W2_ABLATE ? 0 : (int) (M * sizeof(float2)), 0x00020000);
 
 #ifdef BIOEM_W2_STAMPS

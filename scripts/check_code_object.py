@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
 """Reads the gfx950 code object out of bioem_amd/lib/libbioem_hip.so (no GPU needed) and prints one row per kernel:
 registers, LDS, scratch, spills.  Exit code 1 when a shipped kernel spills vector registers or uses scratch memory
-(`.vgpr_spill_count` / `.private_segment_fixed_size` in the code-object notes) -- `make -C bioem_amd/csrc check` and
-__graft_entry__.build() run it, so such a kernel fails the build.
+(`.vgpr_spill_count` / `.private_segment_fixed_size` in the code-object notes), or when a memory instruction of any
+kernel sits in a waterfall loop (disassembly) -- `make -C bioem_amd/csrc check` and __graft_entry__.build() run it, so
+such a kernel fails the build.
 
 usage: scripts/check_code_object.py [--json out.json] [--allow REGEX] [--so path] [--quiet]
 """
@@ -60,6 +61,35 @@ def kernels_of(co):
     return ks
 
 
+def waterfall_kernels(co):
+    """Kernels in which a memory instruction sits in a waterfall loop (its buffer descriptor or address ended up in
+    vector registers: 4 v_readfirstlane + 2 v_cmp + exec juggling around every load)."""
+    dis = subprocess.check_output([os.path.join(LLVM, "llvm-objdump"), "-d", "--no-show-raw-insn", co], text=True)
+    out, name, body = [], None, []
+
+    def flush():
+        if name is None:
+            return
+        n = 0
+        for t, ln in enumerate(body):
+            if "buffer_load" in ln or "buffer_store" in ln or "global_load" in ln or "global_store" in ln:
+                ctx = " ".join(body[max(0, t - 6):t])
+                if "v_readfirstlane_b32" in ctx and "s_and_saveexec_b64" in ctx:
+                    n += 1
+        if n:
+            out.append((name, n))
+
+    for ln in dis.split("\n"):
+        m = re.match(r"^[0-9a-f]+ <(.*)>:$", ln)
+        if m:
+            flush()
+            name, body = m.group(1), []
+        else:
+            body.append(ln)
+    flush()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--so", default=os.path.join(ROOT, "bioem_amd", "lib", "libbioem_hip.so"))
@@ -68,7 +98,9 @@ def main():
     ap.add_argument("--quiet", action="store_true")
     a = ap.parse_args()
     with tempfile.TemporaryDirectory() as d:
-        ks = kernels_of(extract_code_object(a.so, d))
+        co = extract_code_object(a.so, d)
+        ks = kernels_of(co)
+        wf = waterfall_kernels(co)
     names = demangle([k.get("name", k.get("symbol", "?")) for k in ks])
     rows = []
     for k, n in zip(ks, names):
@@ -93,6 +125,11 @@ def main():
     if a.json:
         with open(a.json, "w") as f:
             json.dump({"kernels": rows, "spilling": [r["kernel"] for r in bad]}, f, indent=1)
+    if wf:
+        print("FAIL: memory instructions inside waterfall loops (non-uniform descriptor / address):", file=sys.stderr)
+        for n, c in zip(demangle([w[0] for w in wf]), [w[1] for w in wf]):
+            print("  %s: %d" % (short(n), c), file=sys.stderr)
+        sys.exit(1)
     if bad:
         print("FAIL: kernels with vector-register spills / scratch:", file=sys.stderr)
         for r in bad:
