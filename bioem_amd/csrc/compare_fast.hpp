@@ -517,7 +517,8 @@ __global__ __launch_bounds__(256, fast_waves_per_simd(WD, R)) void k_compare_fas
         xi[FFT_IN(2 * k2p + 1)] = fmaf(c.w, f.z, -(c.z * f.w));
         int tn = k1 * R2 + k2p + RD;
         unsigned vo = laneoff;
-        if (tn >= ttotal)
+        // (only the last RD requests of a k1 step can leave the block: the first test folds at compile time)
+        if (k2p + RD >= R2 && tn >= ttotal)
         { // last steps of this block: run on into the next block (or re-read the last row at the very end)
           tn = has_next ? tn - ttotal : ttotal - 1;
           vo = has_next ? laneoff_next : laneoff;

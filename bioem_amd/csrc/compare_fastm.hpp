@@ -146,7 +146,8 @@ __global__ __launch_bounds__(256, 3) void k_compare_fastm(const CompareArgs a)
         xi[FFT_IN(2 * k2p + 1)] = fmaf(c.w, f.z, -(c.z * f.w));
         int tn = k1 * R2 + k2p + RD;
         unsigned vo = laneoff;
-        if (tn >= ttotal)
+        // (only the last RD requests of a k1 step can leave the block: the first test folds at compile time)
+        if (k2p + RD >= R2 && tn >= ttotal)
         {
           tn = has_next ? tn - ttotal : ttotal - 1;
           vo = has_next ? laneoff_next : laneoff;
