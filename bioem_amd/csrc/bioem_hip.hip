@@ -444,14 +444,28 @@ int launch_compare_fold(bioem_hip_ctx *h, const BatchBuf &bb, int nOC, int orien
 // Above 64 KiB a launch needs the explicit opt-in; 32 N <= 160 KiB bounds the image size at 5120 pixels (the
 // reference's MRC reader stops at 5000, mrc.h:128-133).
 const int kMaxPixels = 5120;
+// the exact-DFT kernels keep a row / column (and their intermediate) in LDS; up to kDftTwLds pixels the twiddle table, too
+constexpr int kDftTwLds = 3072;
+size_t dft_rows_lds(int N) { return sizeof(double) * ((N <= kDftTwLds ? 5 : 3) * (size_t) N + 2); }
+size_t dft_cols_lds(int N) { return sizeof(double2) * (N <= kDftTwLds ? 3 : 2) * (size_t) N; }
 hipError_t dft_allow_lds(int N)
 {
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_dft_rows), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                     (int) (sizeof(double) * (3 * (size_t) N + 2)));
+  hipError_t e;
+  if (N <= kDftTwLds)
+  {
+    e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_dft_rows<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int) dft_rows_lds(N));
+    if (e != hipSuccess)
+      return e;
+    return hipFuncSetAttribute(reinterpret_cast<const void *>(k_dft_cols<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (int) dft_cols_lds(N));
+  }
+  e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_dft_rows<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                          (int) dft_rows_lds(N));
   if (e != hipSuccess)
     return e;
-  return hipFuncSetAttribute(reinterpret_cast<const void *>(k_dft_cols), hipFuncAttributeMaxDynamicSharedMemorySize,
-                             (int) (sizeof(double2) * 2 * (size_t) N));
+  return hipFuncSetAttribute(reinterpret_cast<const void *>(k_dft_cols<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                             (int) dft_cols_lds(N));
 }
 
 void dft_split(int N, int &A, int &B)
@@ -469,11 +483,19 @@ int run_r2c(bioem_hip_ctx *h, const BatchBuf &bb, hipStream_t st, const double *
   const int N = h->N, H = h->H;
   int A, B;
   dft_split(N, A, B);
-  hipLaunchKernelGGL(k_dft_rows, dim3(N, nImg), dim3(128), sizeof(double) * (3 * N + 2), st, srcD, srcF, bb.tempDen,
-                     h->NormDen, N, H, A, B, h->dTwD, bb.rowSpec);
+  if (N <= kDftTwLds)
+    hipLaunchKernelGGL(k_dft_rows<true>, dim3(N, nImg), dim3(128), dft_rows_lds(N), st, srcD, srcF, bb.tempDen,
+                       h->NormDen, N, H, A, B, h->dTwD, bb.rowSpec);
+  else
+    hipLaunchKernelGGL(k_dft_rows<false>, dim3(N, nImg), dim3(128), dft_rows_lds(N), st, srcD, srcF, bb.tempDen,
+                       h->NormDen, N, H, A, B, h->dTwD, bb.rowSpec);
   HIP_CHECK(h, hipGetLastError());
-  hipLaunchKernelGGL(k_dft_cols, dim3(H, nImg), dim3(256), sizeof(double2) * 2 * N, st, bb.rowSpec, N, H, A, B,
-                     h->dTwD, bb.specRef);
+  if (N <= kDftTwLds)
+    hipLaunchKernelGGL(k_dft_cols<true>, dim3(H, nImg), dim3(256), dft_cols_lds(N), st, bb.rowSpec, N, H, A, B,
+                       h->dTwD, bb.specRef);
+  else
+    hipLaunchKernelGGL(k_dft_cols<false>, dim3(H, nImg), dim3(256), dft_cols_lds(N), st, bb.rowSpec, N, H, A, B,
+                       h->dTwD, bb.specRef);
   HIP_CHECK(h, hipGetLastError());
   return 0;
 }
@@ -1693,9 +1715,18 @@ int bioem_hip_r2c(int device, int N, int nImg, const float *in, float *out)
   {
     int A, B;
     dft_split(N, A, B);
-    hipLaunchKernelGGL(k_dft_rows, dim3(N, nImg), dim3(128), sizeof(double) * (3 * N + 2), 0, nullptr, dIn, nullptr,
-                       1.f, N, H, A, B, dTw, dRow);
-    hipLaunchKernelGGL(k_dft_cols, dim3(H, nImg), dim3(256), sizeof(double2) * 2 * N, 0, dRow, N, H, A, B, dTw, dOut);
+    if (N <= kDftTwLds)
+    {
+      hipLaunchKernelGGL(k_dft_rows<true>, dim3(N, nImg), dim3(128), dft_rows_lds(N), 0, nullptr, dIn, nullptr, 1.f, N, H,
+                         A, B, dTw, dRow);
+      hipLaunchKernelGGL(k_dft_cols<true>, dim3(H, nImg), dim3(256), dft_cols_lds(N), 0, dRow, N, H, A, B, dTw, dOut);
+    }
+    else
+    {
+      hipLaunchKernelGGL(k_dft_rows<false>, dim3(N, nImg), dim3(128), dft_rows_lds(N), 0, nullptr, dIn, nullptr, 1.f, N, H,
+                         A, B, dTw, dRow);
+      hipLaunchKernelGGL(k_dft_cols<false>, dim3(H, nImg), dim3(256), dft_cols_lds(N), 0, dRow, N, H, A, B, dTw, dOut);
+    }
     if (hipGetLastError() == hipSuccess &&
         hipMemcpy(out, dOut, sizeof(float2) * M * nImg, hipMemcpyDeviceToHost) == hipSuccess)
       rc = 0;

@@ -54,9 +54,9 @@ __device__ unsigned long long g_w2_stamps[16];
 // blocks per CU, and larger images / windows keep a register-sized share per wave
 template <int R, int NRW, int NBLK, bool NYQ, int HALVES = 1, int NW = 4>
 // waves per SIMD the registers must allow: the T block in halves means its LDS footprint holds a CU to two blocks anyway
-__global__ __launch_bounds__(64 * NW, HALVES == 2 ? (NW == 8 ? 1 : 2)
-                                      : NW == 8   ? ((NRW * NBLK <= 26 && R <= 16) ? 4 : 2)
-                                                  : ((NRW * NBLK <= 42 && R <= 16) ? 3 : 2)) void k_compare_wide2(const CompareArgs a)
+__global__ __launch_bounds__(64 * NW, NW == 8 ? ((NRW * NBLK <= 26 && R <= 16) ? 4 : 2)
+                                      : HALVES == 2 ? 2
+                                                    : ((NRW * NBLK <= 42 && R <= 16) ? 3 : 2)) void k_compare_wide2(const CompareArgs a)
 {
   constexpr int R2 = R / 2;
   // depth of the operand ring (divides R2): the first RD row pairs of a wave's next step are issued before the

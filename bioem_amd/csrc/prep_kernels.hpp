@@ -153,12 +153,20 @@ __global__ void k_project(const bioem_hip_model_point *__restrict__ pts, int nPt
 // Both passes use one Cooley-Tukey split N = A*B (A the largest divisor <= sqrt(N); A = 1 for prime N):
 //   Y[j1][kb] = sum_{j2<B} x[A*j2 + j1] * w_B^(j2*kb),   X[k] = sum_{j1<A} w_N^(j1*k) * Y[j1][k mod B]
 // i.e. N*(A+B) instead of N*N terms per 1-D transform, still exact-DFT arithmetic in double.
+// TWLDS: the twiddle table sits in LDS as well (every term of both passes reads one entry); images too large for
+// that (beyond ~3 400 pixels) read it from global memory as before
+template <bool TWLDS>
 __global__ void k_dft_rows(const double *__restrict__ srcD, const float *__restrict__ srcF,
                            const double *__restrict__ tempden, float NormDen, int N, int H, int A, int B,
                            const double2 *__restrict__ twD, double2 *__restrict__ rowspec)
 {
-  extern __shared__ double srow[];          // N doubles, then N double2
+  extern __shared__ double srow[];          // N doubles, then N double2 (Y), then N double2 (twiddles)
   double2 *Y = reinterpret_cast<double2 *>(srow + N + (N & 1));
+  double2 *twl = Y + N;
+  if (TWLDS)
+    for (int j = threadIdx.x; j < N; j += blockDim.x)
+      twl[j] = twD[j];
+  const double2 *tw = TWLDS ? twl : twD;
   const int i = blockIdx.x, b = blockIdx.y;
   float ratio = 1.f;
   if (srcD)
@@ -184,7 +192,7 @@ __global__ void k_dft_rows(const double *__restrict__ srcD, const float *__restr
     const int step = (A * kb) % N;
     for (int j2 = 0; j2 < B; j2++)
     {
-      const double2 w = twD[idx];
+      const double2 w = tw[idx];
       const double x = srow[A * j2 + j1];
       ar = fma(x, w.x, ar);
       ai = fma(-x, w.y, ai); // forward: e^{-i}
@@ -202,7 +210,7 @@ __global__ void k_dft_rows(const double *__restrict__ srcD, const float *__restr
     int idx = 0;
     for (int j1 = 0; j1 < A; j1++)
     {
-      const double2 w = twD[idx]; // multiply by conj(w)
+      const double2 w = tw[idx]; // multiply by conj(w)
       const double2 y = Y[j1 * B + kb];
       ar = fma(y.x, w.x, ar);
       ar = fma(y.y, w.y, ar);
@@ -216,12 +224,18 @@ __global__ void k_dft_rows(const double *__restrict__ srcD, const float *__restr
   }
 }
 
+template <bool TWLDS>
 __global__ void k_dft_cols(const double2 *__restrict__ rowspec, int N, int H, int A, int B,
                            const double2 *__restrict__ twD, float2 *__restrict__ out)
 {
   extern __shared__ double srow[];
   double2 *col = reinterpret_cast<double2 *>(srow);
   double2 *Y = col + N;
+  double2 *twl = Y + N;
+  if (TWLDS)
+    for (int i = threadIdx.x; i < N; i += blockDim.x)
+      twl[i] = twD[i];
+  const double2 *tw = TWLDS ? twl : twD;
   const int k = blockIdx.x, b = blockIdx.y;
   for (int i = threadIdx.x; i < N; i += blockDim.x)
     col[i] = rowspec[((size_t) b * N + i) * H + k];
@@ -234,7 +248,7 @@ __global__ void k_dft_cols(const double2 *__restrict__ rowspec, int N, int H, in
     const int step = (A * kb) % N;
     for (int j2 = 0; j2 < B; j2++)
     {
-      const double2 w = twD[idx];
+      const double2 w = tw[idx];
       const double2 x = col[A * j2 + j1];
       ar = fma(x.x, w.x, ar);
       ar = fma(x.y, w.y, ar);
@@ -254,7 +268,7 @@ __global__ void k_dft_cols(const double2 *__restrict__ rowspec, int N, int H, in
     int idx = 0;
     for (int j1 = 0; j1 < A; j1++)
     {
-      const double2 w = twD[idx];
+      const double2 w = tw[idx];
       const double2 y = Y[j1 * B + kb];
       ar = fma(y.x, w.x, ar);
       ar = fma(y.y, w.y, ar);
