@@ -172,7 +172,10 @@ int bioem_hip_merge_host(int nShards, int nMaps, int nAngles, int writeAngles, c
  * gathered shards (log-sum-exp of Total / Constoadd, arg-max record from the lowest shard holding the maximum =
  * lowest orientation index; candidates by the heap rule) and the result is copied to the host.
  * pProbMaps_host = [nMaps] bioem_hip_prob_map, cand_host = [nMaps][K] or NULL when K == 0.  Call after every handle's
- * finish_run.  The communicator is created on first use (ncclCommInitAll) and cached; librccl.so is loaded lazily. */
+ * finish_run.  The communicator is created on first use (ncclCommInitAll) and cached; librccl.so is loaded lazily.
+ * Threading: ONE thread hands over all handles of a merge; calls are serialised process-wide (a mutex spans communicator
+ * creation and the grouped all-gather), so merges of different handle sets from different threads queue -- they cannot
+ * interleave their RCCL group calls. */
 int bioem_hip_merge(bioem_hip_handle *handles, int n, void *pProbMaps_host, int K, double numconst,
                     bioem_hip_angle_candidate *cand_host);
 
