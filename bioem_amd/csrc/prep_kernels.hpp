@@ -334,16 +334,12 @@ __global__ void k_convolve(const float2 *__restrict__ proj, const float2 *__rest
   float *S = scratch + (size_t) oc * M4;
   const int even = ((N & 1) == 0);
   const int jend = even ? H - 1 : H;
-  for (int e = threadIdx.x; e < M; e += blockDim.x)
-  {
-    const int i = e / H, j = e - i * H;
-    const float2 p = P[e], k = K[e];
-    float2 o;
+  // one spectrum element: product, its Parseval term at its place in the reference's summation order
+  auto element = [&](int i, int j, float2 &o) {
+    const float2 p = P[(size_t) i * H + j], k = K[(size_t) i * H + j];
     o.x = (p.x * k.x + p.y * k.y);
     o.y = (p.y * k.x - p.x * k.y);
-    O[layout_index(fast, N1, H, i, j)] = o;
     const float t = o.x * o.x + o.y * o.y;
-    // position of this term in the reference's summation order
     int pos;
     if (j >= 1 && j < jend)
       pos = i * H + (j - 1);
@@ -352,7 +348,7 @@ __global__ void k_convolve(const float2 *__restrict__ proj, const float2 *__rest
     else
       pos = i * H + jend; // j == H-1, even N
     S[pos] = (j >= 1 && j < jend) ? t * 2 : t;
-    if (e == 0)
+    if (i == 0 && j == 0)
     {
       bioem_hip_param5 r;
       r.amp = ctfParam[3 * c + 0];
@@ -362,7 +358,29 @@ __global__ void k_convolve(const float2 *__restrict__ proj, const float2 *__rest
       r.sumsquareC = 0.f; // k_parseval_ordered
       params[oc] = r;
     }
+  };
+  if (fast)
+  { // comparison layout: the rows kx = N1 (2 k2p) + k1 and kx + N1 of a (k1, k2 pair) sit side by side -- one thread
+    // forms both and writes them as ONE 16-byte word, consecutive threads (ky) consecutive words
+    for (int e = threadIdx.x; e < (M >> 1); e += blockDim.x)
+    {
+      const int rp = e / H, j = e - rp * H; // row pair rp = k1 * fast + k2p
+      const int k1 = rp / fast, k2p = rp - k1 * fast;
+      const int i0 = N1 * (2 * k2p) + k1;
+      float2 o0, o1;
+      element(i0, j, o0);
+      element(i0 + N1, j, o1);
+      reinterpret_cast<float4 *>(O)[(size_t) rp * H + j] = make_float4(o0.x, o0.y, o1.x, o1.y);
+    }
   }
+  else
+    for (int e = threadIdx.x; e < M; e += blockDim.x)
+    {
+      const int i = e / H, j = e - i * H;
+      float2 o;
+      element(i, j, o);
+      O[(size_t) i * H + j] = o;
+    }
 }
 
 __global__ __launch_bounds__(64) void k_parseval_ordered(const float *__restrict__ scratch, int M, int M4, int nSpec,
