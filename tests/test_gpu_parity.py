@@ -860,7 +860,11 @@ def test_config5_shape_two_shards_device_top_k(tmp_path):
                                               (224, 5, 1, 1), (128, 10, 2, 1), (64, 0, 1, 1), (96, 20, 4, 1),
                                               (80, 4, 2, 1), (224, 10, 2, 1),
                                               # ... which the largest sizes run on the 21-row template
-                                              (400, 5, 1, 1), (360, 4, 1, 1)])
+                                              (400, 5, 1, 1), (360, 4, 1, 1),
+                                              # windows no single kernel covers -> tiles of k_compare_fastm / k_compare_fast
+                                              # (Nyquist split beyond +-42 px, 101 rows, images beyond 512 pixels)
+                                              (128, 45, 1, 1), (130, 50, 1, 1), (256, 47, 1, 1), (600, 18, 1, 1),
+                                              (520, 40, 1, 1), (100, 45, 3, 1)])
 @pytest.mark.parametrize("algo", [1, 2])
 def test_image_sizes_against_oracle(N, maxD, grid, fast, algo):
     from bioem_amd.synthetic import Workload
