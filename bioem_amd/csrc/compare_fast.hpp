@@ -350,33 +350,19 @@ __device__ __forceinline__ void window_accumulate(const float2 *Tl, const float2
 // (an inlined or called summation) pushes the register allocation of the main loop into scratch.
 // GS (1..4): row stride of the window in pixels.  T row m (-WD..WD) holds displacement dx = m*GS, so a coarse
 // DISPLACE_CENTER grid whose offsets are all multiples of GS reaches +-15*GS pixels with the same 2*WD+1 rows.
-// 31-row window (WD = 15): 62 T accumulators.  With a 32-point register FFT that is 205 VGPRs = 2 waves per SIMD;
-// with R <= 16 the kernel fits the 168 VGPRs of 3 waves per SIMD, provided the T block goes through LDS 32 columns at
-// a time (half-width exchange: 68 -> 37 KiB of LDS per block, so that three blocks fit on a CU).
-#ifndef BIOEM_WIDE_WINDOW_3WAVES
-#define BIOEM_WIDE_WINDOW_3WAVES 1
-#endif
-__host__ __device__ constexpr bool fast_half_t(int WD, int R)
-{
-  return BIOEM_WIDE_WINDOW_3WAVES && WD > 10 && R <= 16;
-}
-__host__ __device__ constexpr int fast_waves_per_simd(int WD, int R)
-{
-  return WD <= 10 ? BIOEM_FAST_WAVES_PER_SIMD : (fast_half_t(WD, R) ? 3 : 2);
-}
-
+// (27- and 31-row windows: k_compare_fastm, compare_fastm.hpp)
 template <int WD, int R, bool NYQ, int GS>
-__global__ __launch_bounds__(256, fast_waves_per_simd(WD, R)) void k_compare_fast(const CompareArgs a)
+__global__ __launch_bounds__(256, BIOEM_FAST_WAVES_PER_SIMD) void k_compare_fast(const CompareArgs a)
 {
-  constexpr bool HALF = fast_half_t(WD, R);
+  static_assert(WD <= 10, "windows of at most 21 rows; 27 / 31 rows: k_compare_fastm");
   constexpr int NW = 2 * WD + 1;
   constexpr int R2 = R / 2;            // rows (k2 pairs) per k1 step
   // depth of the operand ring: must divide R2 so that a ring slot is a compile-time function of the k2 pair
   // (R = 30: a ring of 3, not 5 -- 16 registers the 21-row window of that length needs)
   constexpr int RD = (R2 % 4 == 0) ? 4 : (R2 == 15) ? 3 : (R2 % 5 == 0) ? 5 : (R2 % 3 == 0) ? 3 : (R2 % 2 == 0) ? 2 : 1;
-  constexpr int NR = (WD <= 5) ? 3 : (WD <= 10) ? 7 : 16; // accumulators (window rows) per lane
+  constexpr int NR = (WD <= 5) ? 3 : 7; // accumulators (window rows) per lane
   // T row stride in float2 (64 or 32 columns + 2 pad: row groups land on different banks)
-  constexpr int TS = HALF ? 34 : 66;
+  constexpr int TS = 66;
   extern __shared__ __align__(16) unsigned char smem[];
   const int N = a.N, H = a.H, N1 = a.N1;
   float2 *twl = reinterpret_cast<float2 *>(smem);                            // N+1 (+pad)
@@ -552,22 +538,17 @@ __global__ __launch_bounds__(256, fast_waves_per_simd(WD, R)) void k_compare_fas
       wgt = 0.f;
     // T block of THIS wave only: LDS operations of one wave execute in order, so a wave-level fence (no
     // s_barrier) is enough; BIOEM_BLOCK_BARRIER=1 restores block barriers (keeps the 4 waves in lock-step)
-#pragma unroll
-    for (int hh = 0; hh < (HALF ? 2 : 1); hh++)
     {
       WAVE_OR_BLOCK_SYNC(); // previous window reads are done
-      if (!HALF || (lane >> 5) == hh)
-      {
 #pragma unroll
-        for (int d = 0; d < NW; d++)
-          Tl[d * TS + (HALF ? (lane & 31) : lane)] = make_float2(Tr[d] * wgt, Ti[d] * wgt);
-      }
+      for (int d = 0; d < NW; d++)
+        Tl[d * TS + lane] = make_float2(Tr[d] * wgt, Ti[d] * wgt);
       WAVE_OR_BLOCK_SYNC();
-      const int idx0 = (int) (((long long) (blk * 64 + hh * 32) * step) % N);
+      const int idx0 = (int) (((long long) (blk * 64) * step) % N);
       if (is_static)
       {
         const int rowoff[NR] = {rowbase};
-        window_accumulate<NR, true, HALF ? 16 : 32, TS>(Tl, twl, N, step, idx0, rowoff, nr, acc);
+        window_accumulate<NR, true, 32, TS>(Tl, twl, N, step, idx0, rowoff, nr, acc);
       }
       else
       {
@@ -575,7 +556,7 @@ __global__ __launch_bounds__(256, fast_waves_per_simd(WD, R)) void k_compare_fas
 #pragma unroll
         for (int r = 0; r < NR; r++)
           rowoff[r] = row_of(r);
-        window_accumulate<NR, false, HALF ? 16 : 32, TS>(Tl, twl, N, step, idx0, rowoff, nr, acc);
+        window_accumulate<NR, false, 32, TS>(Tl, twl, N, step, idx0, rowoff, nr, acc);
       }
     }
   }
