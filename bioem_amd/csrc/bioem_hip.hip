@@ -137,6 +137,8 @@ struct bioem_hip_ctx
   int nPts = 0;
   float NormDen = 0, pixelSize = 0;
   int shiftX = 0, shiftY = 0;
+  int iradMax = 0; // widest sphere footprint of the model, pixels (k_project_bands)
+  int nCU = 256;   // compute units of the device: size of the resident grids of the preparation kernels
   float4 *dAngles = nullptr;
   int nAnglesUp = 0, isQuat = 1;
   float2 *dTw = nullptr;   // N+1 entries exp(+2 pi i k/N), float
@@ -212,6 +214,7 @@ struct bioem_hip_ctx
 };
 
 #include "prep_kernels.hpp"
+#include "dft_mfma.hpp"
 #include "posterior.hpp"
 #include "fft_registers.hpp"
 #include "compare_args.hpp"
@@ -448,9 +451,38 @@ const int kMaxPixels = 5120;
 constexpr int kDftTwLds = 3072;
 size_t dft_rows_lds(int N) { return sizeof(double) * ((N <= kDftTwLds ? 5 : 3) * (size_t) N + 2); }
 size_t dft_cols_lds(int N) { return sizeof(double2) * (N <= kDftTwLds ? 3 : 2) * (size_t) N; }
+void dft_split(int N, int &A, int &B)
+{
+  A = 1;
+  for (int d = 1; d * d <= N; d++)
+    if (N % d == 0)
+      A = d;
+  B = N / A;
+}
+bool dft_use_mfma(int N)
+{
+  int A, B;
+  dft_split(N, A, B);
+  return dft_mfma_fits(N, A, B) && !getenv("BIOEM_DFT_VECTOR");
+}
 hipError_t dft_allow_lds(int N)
 {
   hipError_t e;
+  if (dft_use_mfma(N))
+  {
+    const void *fns[4] = {reinterpret_cast<const void *>(k_dft_rows_mfma<2>),
+                          reinterpret_cast<const void *>(k_dft_rows_mfma<kDftMfmaTiles>),
+                          reinterpret_cast<const void *>(k_dft_cols_mfma<2>),
+                          reinterpret_cast<const void *>(k_dft_cols_mfma<kDftMfmaTiles>)};
+    for (int f = 0; f < 4; f++)
+    {
+      e = hipFuncSetAttribute(fns[f], hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int) (f < 2 ? dft_mfma_rows_lds(N) : dft_mfma_cols_lds(N)));
+      if (e != hipSuccess)
+        return e;
+    }
+    return hipSuccess;
+  }
   if (N <= kDftTwLds)
   {
     e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_dft_rows<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -468,45 +500,78 @@ hipError_t dft_allow_lds(int N)
                              (int) dft_cols_lds(N));
 }
 
-void dft_split(int N, int &A, int &B)
+// r2c of nImg images (double projection maps scaled by NormDen / tempden, or float maps) into `out` (reference layout);
+// rowSpec holds the row pass (N x H double2 per image).  dft_allow_lds(N) must have run on this device.
+hipError_t launch_r2c(hipStream_t st, int nCU, const double *srcD, const float *srcF, const double *tempDen, float NormDen,
+                      int N, int nImg, const double2 *tw, double2 *rowSpec, float2 *out)
 {
-  A = 1;
-  for (int d = 1; d * d <= N; d++)
-    if (N % d == 0)
-      A = d;
-  B = N / A;
-}
-
-// r2c of nImg images (either double projection maps with tempden scaling, or float maps) into bb.specRef
-int run_r2c(bioem_hip_ctx *h, const BatchBuf &bb, hipStream_t st, const double *srcD, const float *srcF, int nImg)
-{
-  const int N = h->N, H = h->H;
+  const int H = N / 2 + 1;
   int A, B;
   dft_split(N, A, B);
-  if (N <= kDftTwLds)
-    hipLaunchKernelGGL(k_dft_rows<true>, dim3(N, nImg), dim3(128), dft_rows_lds(N), st, srcD, srcF, bb.tempDen,
-                       h->NormDen, N, H, A, B, h->dTwD, bb.rowSpec);
+  if (dft_use_mfma(N))
+  {
+    // resident grids: as many blocks as the LDS of the device holds at once
+    const int perCU = std::max(1, std::min(4, (int) (160 * 1024 / (dft_mfma_cols_lds(N) + 1024))));
+    const int rowUnits = ((N + 15) / 16) * nImg, colUnits = ((H + 15) / 16) * nImg;
+    if (A * ((B + 15) / 16) <= 2 * kDftMfmaWaves)
+    {
+      hipLaunchKernelGGL(k_dft_rows_mfma<2>, dim3(std::min(rowUnits, perCU * nCU)), dim3(kDftMfmaThreads),
+                         dft_mfma_rows_lds(N), st, srcD, srcF, tempDen, NormDen, N, H, A, B, nImg, tw, rowSpec);
+      hipLaunchKernelGGL(k_dft_cols_mfma<2>, dim3(std::min(colUnits, perCU * nCU)), dim3(kDftMfmaThreads),
+                         dft_mfma_cols_lds(N), st, rowSpec, N, H, A, B, nImg, tw, out);
+    }
+    else
+    {
+      // registers hold one block of this variant per CU
+      hipLaunchKernelGGL(k_dft_rows_mfma<kDftMfmaTiles>, dim3(std::min(rowUnits, nCU)), dim3(kDftMfmaThreads),
+                         dft_mfma_rows_lds(N), st, srcD, srcF, tempDen, NormDen, N, H, A, B, nImg, tw, rowSpec);
+      hipLaunchKernelGGL(k_dft_cols_mfma<kDftMfmaTiles>, dim3(std::min(colUnits, nCU)), dim3(kDftMfmaThreads),
+                         dft_mfma_cols_lds(N), st, rowSpec, N, H, A, B, nImg, tw, out);
+    }
+  }
+  else if (N <= kDftTwLds)
+  {
+    hipLaunchKernelGGL(k_dft_rows<true>, dim3(N, nImg), dim3(128), dft_rows_lds(N), st, srcD, srcF, tempDen, NormDen, N,
+                       H, A, B, tw, rowSpec);
+    hipLaunchKernelGGL(k_dft_cols<true>, dim3(H, nImg), dim3(256), dft_cols_lds(N), st, rowSpec, N, H, A, B, tw, out);
+  }
   else
-    hipLaunchKernelGGL(k_dft_rows<false>, dim3(N, nImg), dim3(128), dft_rows_lds(N), st, srcD, srcF, bb.tempDen,
-                       h->NormDen, N, H, A, B, h->dTwD, bb.rowSpec);
-  HIP_CHECK(h, hipGetLastError());
-  if (N <= kDftTwLds)
-    hipLaunchKernelGGL(k_dft_cols<true>, dim3(H, nImg), dim3(256), dft_cols_lds(N), st, bb.rowSpec, N, H, A, B,
-                       h->dTwD, bb.specRef);
-  else
-    hipLaunchKernelGGL(k_dft_cols<false>, dim3(H, nImg), dim3(256), dft_cols_lds(N), st, bb.rowSpec, N, H, A, B,
-                       h->dTwD, bb.specRef);
-  HIP_CHECK(h, hipGetLastError());
+  {
+    hipLaunchKernelGGL(k_dft_rows<false>, dim3(N, nImg), dim3(128), dft_rows_lds(N), st, srcD, srcF, tempDen, NormDen, N,
+                       H, A, B, tw, rowSpec);
+    hipLaunchKernelGGL(k_dft_cols<false>, dim3(H, nImg), dim3(256), dft_cols_lds(N), st, rowSpec, N, H, A, B, tw, out);
+  }
+  return hipGetLastError();
+}
+
+int run_r2c(bioem_hip_ctx *h, const BatchBuf &bb, hipStream_t st, const double *srcD, const float *srcF, int nImg)
+{
+  HIP_CHECK(h, launch_r2c(st, h->nCU, srcD, srcF, bb.tempDen, h->NormDen, h->N, nImg, h->dTwD, bb.rowSpec, bb.specRef));
   return 0;
 }
 
 int project_batch(bioem_hip_ctx *h, const BatchBuf &bb, hipStream_t st, int o0, int nO)
 {
   const int N = h->N;
-  HIP_CHECK(h, hipMemsetAsync(bb.projReal, 0, sizeof(double) * (size_t) nO * N * N, st));
   HIP_CHECK(h, hipMemsetAsync(bb.tempDen, 0, sizeof(double) * nO, st));
-  hipLaunchKernelGGL(k_project, dim3((h->nPts + 255) / 256, nO), dim3(256), 0, st, h->dPts, h->nPts, h->dAngles, o0,
-                     h->isQuat, N, h->pixelSize, h->shiftX, h->shiftY, bb.projReal, bb.tempDen);
+  const int TR = 40960 / (8 * N); // rows of one LDS band: three blocks per CU
+  // the record of every (orientation, point) borrows the row-pass buffer of the r2c that follows
+  const bool coordsFit = (size_t) h->nPts * sizeof(ProjectRecord) <= (size_t) N * h->H * sizeof(double2);
+  if (TR >= 12 && h->iradMax <= 16 && N < 32768 && coordsFit && !getenv("BIOEM_PROJECT_GLOBAL_ATOMICS"))
+  {
+    ProjectRecord *coords = reinterpret_cast<ProjectRecord *>(bb.rowSpec);
+    hipLaunchKernelGGL(k_project_coords, dim3((h->nPts + 255) / 256, nO), dim3(256), 0, st, h->dPts, h->nPts, h->dAngles,
+                       o0, h->isQuat, N, h->pixelSize, h->shiftX, h->shiftY, coords);
+    const int units = ((N + TR - 1) / TR) * nO;
+    hipLaunchKernelGGL(k_project_bands, dim3(std::min(units, 3 * h->nCU)), dim3(256), sizeof(double) * TR * N, st, coords,
+                       h->nPts, nO, N, TR, h->iradMax, h->pixelSize, bb.projReal, bb.tempDen);
+  }
+  else
+  {
+    HIP_CHECK(h, hipMemsetAsync(bb.projReal, 0, sizeof(double) * (size_t) nO * N * N, st));
+    hipLaunchKernelGGL(k_project, dim3((h->nPts + 255) / 256, nO), dim3(256), 0, st, h->dPts, h->nPts, h->dAngles, o0,
+                       h->isQuat, N, h->pixelSize, h->shiftX, h->shiftY, bb.projReal, bb.tempDen);
+  }
   HIP_CHECK(h, hipGetLastError());
   return run_r2c(h, bb, st, bb.projReal, nullptr, nO);
 }
@@ -681,7 +746,22 @@ static int create_impl(bioem_hip_handle *out, int device, const bioem_hip_param_
     return 2;
   }
   HIP_CHECK(h, hipSetDevice(device));
+  HIP_CHECK(h, hipDeviceGetAttribute(&h->nCU, hipDeviceAttributeMultiprocessorCount, device));
   HIP_CHECK(h, dft_allow_lds(N));
+  if (getenv("BIOEM_PREP_OCCUPANCY"))
+  { // blocks per CU the runtime grants the preparation kernels at this image size
+    int nb = 0;
+    const int TRo = std::max(1, 40960 / (8 * N));
+    hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_project_bands, 256, sizeof(double) * TRo * N);
+    fprintf(stderr, "k_project_bands: %d blocks/CU (dynamic LDS %zu B)\n", nb, sizeof(double) * TRo * N);
+    if (dft_use_mfma(N))
+    {
+      hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_dft_rows_mfma<2>, kDftMfmaThreads, dft_mfma_rows_lds(N));
+      fprintf(stderr, "k_dft_rows_mfma<2>: %d blocks/CU (dynamic LDS %zu B)\n", nb, dft_mfma_rows_lds(N));
+      hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_dft_cols_mfma<2>, kDftMfmaThreads, dft_mfma_cols_lds(N));
+      fprintf(stderr, "k_dft_cols_mfma<2>: %d blocks/CU (dynamic LDS %zu B)\n", nb, dft_mfma_cols_lds(N));
+    }
+  }
   {
     int prLow = 0, prHigh = 0;
     HIP_CHECK(h, hipDeviceGetStreamPriorityRange(&prLow, &prHigh));
@@ -1034,6 +1114,10 @@ int bioem_hip_upload_model(bioem_hip_handle h, const bioem_hip_model_point *pts,
   h->pixelSize = pixelSize;
   h->shiftX = shiftX;
   h->shiftY = shiftY;
+  h->iradMax = 0;
+  for (int n = 0; n < nPts; n++)
+    if (pts[n].radius > pixelSize)
+      h->iradMax = std::max(h->iradMax, (int) (pts[n].radius / pixelSize) + 1);
   return 0;
 }
 
@@ -1704,6 +1788,8 @@ int bioem_hip_r2c(int device, int N, int nImg, const float *in, float *out)
     return 1;
   const int H = N / 2 + 1;
   const size_t M = (size_t) N * H;
+  int nCU = 256;
+  hipDeviceGetAttribute(&nCU, hipDeviceAttributeMultiprocessorCount, device);
   std::vector<double2> twd(N);
   for (int k = 0; k < N; k++)
   {
@@ -1720,21 +1806,7 @@ int bioem_hip_r2c(int device, int N, int nImg, const float *in, float *out)
       hipMemcpy(dTw, twd.data(), sizeof(double2) * N, hipMemcpyHostToDevice) == hipSuccess &&
       hipMemcpy(dIn, in, sizeof(float) * (size_t) N * N * nImg, hipMemcpyHostToDevice) == hipSuccess)
   {
-    int A, B;
-    dft_split(N, A, B);
-    if (N <= kDftTwLds)
-    {
-      hipLaunchKernelGGL(k_dft_rows<true>, dim3(N, nImg), dim3(128), dft_rows_lds(N), 0, nullptr, dIn, nullptr, 1.f, N, H,
-                         A, B, dTw, dRow);
-      hipLaunchKernelGGL(k_dft_cols<true>, dim3(H, nImg), dim3(256), dft_cols_lds(N), 0, dRow, N, H, A, B, dTw, dOut);
-    }
-    else
-    {
-      hipLaunchKernelGGL(k_dft_rows<false>, dim3(N, nImg), dim3(128), dft_rows_lds(N), 0, nullptr, dIn, nullptr, 1.f, N, H,
-                         A, B, dTw, dRow);
-      hipLaunchKernelGGL(k_dft_cols<false>, dim3(H, nImg), dim3(256), dft_cols_lds(N), 0, dRow, N, H, A, B, dTw, dOut);
-    }
-    if (hipGetLastError() == hipSuccess &&
+    if (launch_r2c(0, nCU, nullptr, dIn, nullptr, 1.f, N, nImg, dTw, dRow, dOut) == hipSuccess &&
         hipMemcpy(out, dOut, sizeof(float2) * M * nImg, hipMemcpyDeviceToHost) == hipSuccess)
       rc = 0;
   }

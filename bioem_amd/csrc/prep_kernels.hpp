@@ -49,17 +49,8 @@ __global__ void k_unreorder(const float2 *__restrict__ src, float2 *__restrict__
   }
 }
 
-// ------------------------------------------------------------------------------------------------
-// projection: bioem.cpp:1604-1818 (rotation, point / sphere splat, tempden)
-// one thread per model point, blockIdx.y = orientation inside the batch
-// ------------------------------------------------------------------------------------------------
-__global__ void k_project(const bioem_hip_model_point *__restrict__ pts, int nPts, const float4 *__restrict__ angles,
-                          int o0, int isQuat, int N, float pixelSize, int shiftX, int shiftY,
-                          double *__restrict__ proj, double *__restrict__ tempden)
+__device__ inline void rotation_matrix(const float4 a, int isQuat, float (&rotmat)[3][3])
 {
-  const int ob = blockIdx.y;
-  const float4 a = angles[o0 + ob];
-  float rotmat[3][3];
   if (isQuat)
   {
     const float q0 = a.x, q1 = a.y, q2 = a.z, q3 = a.w; // bioem.cpp:1632-1646
@@ -87,6 +78,19 @@ __global__ void k_project(const bioem_hip_model_point *__restrict__ pts, int nPt
     rotmat[2][1] = -sb * ca;
     rotmat[2][2] = cb;
   }
+}
+
+// ------------------------------------------------------------------------------------------------
+// projection: bioem.cpp:1604-1818 (rotation, point / sphere splat, tempden)
+// one thread per model point, blockIdx.y = orientation inside the batch
+// ------------------------------------------------------------------------------------------------
+__global__ void k_project(const bioem_hip_model_point *__restrict__ pts, int nPts, const float4 *__restrict__ angles,
+                          int o0, int isQuat, int N, float pixelSize, int shiftX, int shiftY,
+                          double *__restrict__ proj, double *__restrict__ tempden)
+{
+  const int ob = blockIdx.y;
+  float rotmat[3][3];
+  rotation_matrix(angles[o0 + ob], isQuat, rotmat);
   double td = 0.;
   const int n = blockIdx.x * blockDim.x + threadIdx.x;
   double *map = proj + (size_t) ob * N * N;
@@ -143,6 +147,159 @@ __global__ void k_project(const bioem_hip_model_point *__restrict__ pts, int nPt
   }
   if (threadIdx.x == 0 && red[0] != 0.)
     atomicAdd(&tempden[ob], red[0]);
+}
+
+// The same projection in two steps, without global atomics or a zero-filled map (used while a band of >= 12 rows fits
+// 40 KiB of LDS, N <= 426):
+//   k_project_coords  rotates every model point once per orientation and leaves a 16-byte record: its pixel
+//                     (i << 16 | j, or -1 when the reference skips it: outside the map / sphere touching the border),
+//                     radius, density and the sphere's half width in pixels (0 for a point);
+//   k_project_bands   one block per band of TR map rows: lists the records that reach the band (512 points at a time,
+//                     2 048 loaded at once), splats them with one thread per (sphere, column of its
+//                     footprint) into LDS with double atomics and stores the band once.
+// The additions are the same doubles in another order; the weight is the reference's expression.
+struct alignas(16) ProjectRecord
+{
+  int ij;
+  float radius, density;
+  int irad;
+};
+
+__global__ void k_project_coords(const bioem_hip_model_point *__restrict__ pts, int nPts,
+                                 const float4 *__restrict__ angles, int o0, int isQuat, int N, float pixelSize,
+                                 int shiftX, int shiftY, ProjectRecord *__restrict__ coords)
+{
+  const int ob = blockIdx.y, n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= nPts)
+    return;
+  float rotmat[3][3];
+  rotation_matrix(angles[o0 + ob], isQuat, rotmat);
+  const bioem_hip_model_point p = pts[n];
+  float rp[3] = {0.f, 0.f, 0.f};
+  for (int k = 0; k < 3; k++)
+    for (int j = 0; j < 3; j++)
+      rp[k] += rotmat[k][j] * p.pos[j];
+  int i = (int) floorf(rp[0] / pixelSize + (float) N / 2.0f + 0.5f);
+  int j = (int) floorf(rp[1] / pixelSize + (float) N / 2.0f + 0.5f);
+  bool ok;
+  int irad = 0;
+  if (p.radius <= pixelSize)
+    ok = !(i < 0 || j < 0 || i >= N || j >= N);
+  else
+  {
+    i -= shiftX;
+    j -= shiftY;
+    irad = (int) (p.radius / pixelSize) + 1;
+    ok = !(i < irad || j < irad || i >= N - irad || j >= N - irad);
+  }
+  ProjectRecord r;
+  r.ij = ok ? (i << 16 | j) : -1;
+  r.radius = p.radius;
+  r.density = p.density;
+  r.irad = irad;
+  coords[(size_t) ob * nPts + n] = r;
+}
+
+constexpr int kProjectList = 512;
+
+__global__ __launch_bounds__(256) void k_project_bands(const ProjectRecord *__restrict__ coords, int nPts, int nO, int N,
+                                                        int TR, int iradMax, float pixelSize, double *__restrict__ proj,
+                                                        double *__restrict__ tempden)
+{
+  extern __shared__ double band[]; // TR x N
+  __shared__ ProjectRecord list[kProjectList];
+  __shared__ int cnt;
+  __shared__ double red[4];
+  const int nBands = (N + TR - 1) / TR;
+  const int S = 2 * iradMax + 1;
+  // a resident grid walks the (orientation, band) units: launching a 50 KiB-LDS block costs more than one short unit
+  for (int unit = blockIdx.x; unit < nO * nBands; unit += gridDim.x)
+  {
+  const int ob = unit / nBands;
+  const int r0 = (unit - ob * nBands) * TR, r1 = min(N, r0 + TR);
+  const ProjectRecord *C = coords + (size_t) ob * nPts;
+  __syncthreads(); // the previous band is stored
+  for (int e = threadIdx.x; e < (r1 - r0) * N; e += blockDim.x)
+    band[e] = 0.;
+  double td = 0.;
+  // 2 048 records per round sit in registers (one wait for global memory), listed and splatted 512 at a time
+  for (int n00 = 0; n00 < nPts; n00 += 4 * kProjectList)
+  {
+    ProjectRecord rec[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++)
+    {
+      const int n = n00 + u * 256 + threadIdx.x;
+      rec[u] = C[min(n, nPts - 1)];
+      rec[u].ij = n < nPts ? rec[u].ij : -1;
+    }
+#pragma unroll
+    for (int g = 0; g < 4; g++)
+    {
+      if (n00 + g * kProjectList >= nPts)
+        break;
+      if (threadIdx.x == 0)
+        cnt = 0;
+      __syncthreads();
+#pragma unroll
+      for (int u = 2 * g; u < 2 * g + 2; u++)
+      {
+        const ProjectRecord r = rec[u];
+        const int i = r.ij >> 16;
+        if (r.ij >= 0 && i + r.irad >= r0 && i - r.irad < r1)
+          list[atomicAdd(&cnt, 1)] = r;
+      }
+      __syncthreads();
+      const int items = cnt * S;
+      for (int it = threadIdx.x; it < items; it += blockDim.x)
+      {
+        const int en = it / S, dj = it - en * S - iradMax;
+        const ProjectRecord q = list[en];
+        const int i = q.ij >> 16, j = q.ij & 0xffff;
+        const float radius = q.radius, density = q.density;
+        if (q.irad == 0)
+        { // a point: bioem.cpp:1700-1712
+          if (dj == 0)
+          {
+            atomicAdd(&band[(i - r0) * N + j], (double) density);
+            td += (double) density;
+          }
+          continue;
+        }
+        if (dj < -q.irad || dj > q.irad)
+          continue;
+        const float rad2 = radius * radius;
+        const int jj = j + dj;
+        for (int ii = max(i - q.irad, r0); ii < min(i + q.irad + 1, r1); ii++)
+        {
+          const float dist = ((float) (ii - i) * (ii - i) + (jj - j) * (jj - j)) * pixelSize * pixelSize;
+          if (dist < rad2)
+          {
+            const double w = (double) (pixelSize * pixelSize * 2 * sqrtf(rad2 - dist) * density * 3) /
+                             (4 * M_PI * radius * rad2);
+            atomicAdd(&band[(ii - r0) * N + jj], w);
+            td += w;
+          }
+        }
+      }
+      __syncthreads(); // the list is rewritten by the next points
+    }
+  }
+  for (int o = 32; o > 0; o >>= 1)
+    td += __shfl_down(td, o);
+  if ((threadIdx.x & 63) == 0)
+    red[threadIdx.x >> 6] = td;
+  __syncthreads(); // also: every splat of this band is done
+  if (threadIdx.x == 0)
+  {
+    const double t = (red[0] + red[1]) + (red[2] + red[3]);
+    if (t != 0.)
+      atomicAdd(&tempden[ob], t);
+  }
+  double *map = proj + (size_t) ob * N * N + (size_t) r0 * N;
+  for (int e = threadIdx.x; e < (r1 - r0) * N; e += blockDim.x)
+    map[e] = band[e];
+  }
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -1,6 +1,7 @@
 #!/bin/bash
 # usage (GPU box): scripts/pmc_quick.sh <tag> [bench flags] -- the SQ issue / activity passes of ONE bench shape and a
-# per-comparison table (quad-cycle units for the *_CYCLES / ACTIVE / WAIT counters).  BIOEM_HIP_LIBRARY is honoured.
+# per-comparison table (quad-cycle units for the *_CYCLES / ACTIVE / WAIT counters).  BIOEM_HIP_LIBRARY is honoured;
+# PMC_KERNEL=<substring> picks another kernel than the dominant k_compare_* one (e.g. k_project_bands).
 tag=$1; shift
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/pmcq_$tag
@@ -11,14 +12,15 @@ B="python3 $R/bench.py --no-cpu-baseline $@ --steps 1 --warmup 0"
 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $O/sqa -- $B > $O/sqa.log 2>&1 &&
 rocprofv3 --kernel-trace --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT --output-format csv -d $O/sqb -- $B > $O/sqb.log 2>&1
 python3 - $O "$tag" <<'PY'
-import csv, glob, sys, statistics, collections
+import csv, glob, os, sys, statistics, collections
+KF = os.environ.get("PMC_KERNEL", "k_compare")
 allv = {}
 kname, nl, dur = None, 0, 0
 for name in ("sqa", "sqb"):
     fs = glob.glob(sys.argv[1] + "/" + name + "/*/*counter_collection.csv") + glob.glob(sys.argv[1] + "/" + name + "/*counter_collection.csv")
     if not fs:
         print(name, "no counter file"); continue
-    rows = [r for r in csv.DictReader(open(fs[0])) if "k_compare" in r["Kernel_Name"]]
+    rows = [r for r in csv.DictReader(open(fs[0])) if KF in r["Kernel_Name"]]
     tot = collections.Counter()
     for r in rows:
         tot[r["Kernel_Name"]] += int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
