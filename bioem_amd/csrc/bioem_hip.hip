@@ -673,6 +673,18 @@ int compat_flush(bioem_hip_ctx *h)
 // conv spectra of CTFs [c0, c0 + nC) of the nO projected orientations, row ob * nC + (c - c0)
 int convolve_batch(bioem_hip_ctx *h, const BatchBuf &bb, hipStream_t st, int nO, int c0, int nC)
 {
+  // few particles: the preparation is the longer half of the pipeline and the fused kernel shortens it (20 particles:
+  // 9.3 -> 8.4 ms per pass); many particles: it hides behind the comparison either way, and the one-wave blocks of
+  // k_parseval_ordered take less from the comparison kernel than the 16-wave blocks of k_convolve_sums (1 000
+  // particles: 53.0 against 52.0 M comparisons/s)
+  const char *fe = getenv("BIOEM_CONVOLVE_FUSED");
+  if (fe ? atoi(fe) != 0 : h->nMaps <= 64)
+  {
+    hipLaunchKernelGGL(k_convolve_sums, dim3((nC + kConvCtfs - 1) / kConvCtfs, nO), dim3(kConvThreads), 0, st, bb.specRef, h->dCTF,
+                       h->dCtfParam, h->N, h->H, h->fast, h->N1, c0, nC, bb.conv, bb.params);
+    HIP_CHECK(h, hipGetLastError());
+    return 0;
+  }
   const int M4 = (int) ((h->M + 3) & ~(size_t) 3);
   hipLaunchKernelGGL(k_convolve, dim3(nC, nO), dim3(256), 0, st, bb.specRef, h->dCTF, h->dCtfParam, h->N, h->H,
                      h->fast, h->N1, c0, bb.conv, bb.scratch, M4, bb.params);

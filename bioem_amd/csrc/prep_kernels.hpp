@@ -613,6 +613,137 @@ __global__ __launch_bounds__(64) void k_parseval_ordered(const float *__restrict
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// k_convolve_sums: the two kernels above in one -- no Parseval terms through global memory.
+// One block per (orientation, group of up to kConvCtfs CTFs).  Waves 1..15 form the products of a tile of kConvTile
+// consecutive positions of the reference's summation order for every CTF of the group (the projection element is read
+// once), store the spectra and leave the terms in LDS; wave 0 adds the previous tile meanwhile, one lane per CTF, one
+// term after the other as the reference does.  In the comparison layout a 16-byte word holds the rows kx and kx + N1:
+// it is written when the first of them comes by (its partner's product is formed there for the store, and once more
+// when its own position in the order is reached: same operands, same bits).
+// ------------------------------------------------------------------------------------------------
+constexpr int kConvTile = 1024;
+constexpr int kConvCtfs = 6;
+constexpr int kConvStride = kConvTile + 4; // chain stride in LDS (floats): the adding lanes read different banks
+
+// block barrier that orders LDS traffic only: __syncthreads() would also wait for the spectra on their way to memory
+__device__ inline void lds_barrier()
+{
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+constexpr int kConvThreads = 1024; // one adding wave, fifteen producing waves: a tile costs them one round of loads
+
+__global__ __launch_bounds__(kConvThreads) void k_convolve_sums(const float2 *__restrict__ proj, const float2 *__restrict__ ctf,
+                                                        const float *__restrict__ ctfParam, int N, int H, int fast,
+                                                        int N1, int c0, int nC, float2 *__restrict__ conv,
+                                                        bioem_hip_param5 *__restrict__ params)
+{
+  __shared__ __align__(16) float terms[2][kConvCtfs][kConvStride];
+  __shared__ float sC[kConvCtfs];
+  const int ob = blockIdx.y, cg = blockIdx.x * kConvCtfs;
+  const int nCb = min(kConvCtfs, nC - cg);
+  const int M = N * H;
+  const int even = ((N & 1) == 0);
+  const int jend = even ? H - 1 : H;
+  const float2 *P = proj + (size_t) ob * M;
+  const float2 *K0 = ctf + (size_t) (c0 + cg) * M;
+  float2 *O0 = conv + ((size_t) ob * nC + cg) * M;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int nt = (M + kConvTile - 1) / kConvTile;
+  auto produce = [&](int t) {
+    float(*T)[kConvStride] = terms[t & 1];
+    for (int e = (int) threadIdx.x - 64; e < kConvTile; e += kConvThreads - 64)
+    {
+      const int pos = t * kConvTile + e;
+      if (pos >= M)
+      { // beyond the spectrum: x + 0 = x
+        for (int c = 0; c < nCb; c++)
+          T[c][e] = 0.f;
+        continue;
+      }
+      const int i = pos / H, r = pos - i * H;
+      const int j = r < jend - 1 ? r + 1 : (r == jend - 1 ? 0 : H - 1);
+      const bool twice = j >= 1 && j < jend;
+      const size_t ij = (size_t) i * H + j;
+      const float2 p = P[ij];
+      bool first = false;
+      float2 p1 = make_float2(0.f, 0.f);
+      size_t word = 0;
+      if (fast)
+      {
+        const int k2 = i / N1, k1 = i - k2 * N1;
+        first = !(k2 & 1);
+        word = (size_t) (k1 * fast + (k2 >> 1)) * H + j;
+        if (first)
+          p1 = P[ij + (size_t) N1 * H];
+      }
+      for (int c = 0; c < nCb; c++)
+      {
+        const float2 *K = K0 + (size_t) c * M;
+        float2 *O = O0 + (size_t) c * M;
+        const float2 k = K[ij];
+        float2 o;
+        o.x = (p.x * k.x + p.y * k.y);
+        o.y = (p.y * k.x - p.x * k.y);
+        const float tt = o.x * o.x + o.y * o.y;
+        T[c][e] = twice ? tt * 2 : tt;
+        if (!fast)
+          O[ij] = o;
+        else if (first)
+        {
+          const float2 k1v = K[ij + (size_t) N1 * H];
+          float2 o1;
+          o1.x = (p1.x * k1v.x + p1.y * k1v.y);
+          o1.y = (p1.y * k1v.x - p1.x * k1v.y);
+          reinterpret_cast<float4 *>(O)[word] = make_float4(o.x, o.y, o1.x, o1.y);
+        }
+        if (i == 0 && j == 0)
+          sC[c] = o.x;
+      }
+    }
+  };
+  if (wave != 0)
+    produce(0);
+  else
+    __builtin_amdgcn_s_setprio(3); // the adding wave is the critical path: it issues ahead of the producers of its SIMD
+  lds_barrier();
+  float ss = 0.f;
+  for (int t = 0; t < nt; t++)
+  {
+    if (wave == 0)
+    {
+      if (lane < nCb)
+      {
+        const float4 *q = reinterpret_cast<const float4 *>(&terms[t & 1][lane][0]);
+#pragma unroll 8
+        for (int k = 0; k < kConvTile / 4; k++)
+        {
+          const float4 v = q[k];
+          ss += v.x;
+          ss += v.y;
+          ss += v.z;
+          ss += v.w;
+        }
+      }
+    }
+    else if (t + 1 < nt)
+      produce(t + 1);
+    lds_barrier();
+  }
+  if (wave == 0 && lane < nCb)
+  {
+    const int c = c0 + cg + lane;
+    bioem_hip_param5 r;
+    r.amp = ctfParam[3 * c + 0];
+    r.pha = ctfParam[3 * c + 1];
+    r.env = ctfParam[3 * c + 2];
+    r.sumC = sC[lane];
+    r.sumsquareC = ss / (float) (N * N);
+    params[(size_t) ob * nC + cg + lane] = r;
+  }
+}
+
 // sums only (compat entry supplies conv spectra but we never trust host params blindly: they are used as given)
 
 } // namespace

@@ -186,6 +186,24 @@ def test_device_projection_and_convolution(name):
     E.close()
 
 
+@pytest.mark.parametrize("name", ["g10_n64", "g9_n35_odd", "g7_n224", "g19_n200"])
+def test_fused_convolution_equals_the_two_kernel_one(name, monkeypatch):
+    """k_convolve_sums (few particles) and k_convolve + k_parseval_ordered (many) are the same arithmetic in the same
+    order: spectra, sumC and sumsquareC agree to the bit for every CTF."""
+    case, S = setup_for(name)
+    E = make_engine(S, 1)
+    for io in [0, S.nAngles - 1]:
+        for c in range(S.nCTF):
+            monkeypatch.setenv("BIOEM_CONVOLVE_FUSED", "1")
+            a = E.debug_convolution(io, c)
+            monkeypatch.setenv("BIOEM_CONVOLVE_FUSED", "0")
+            b = E.debug_convolution(io, c)
+            assert a[0].tobytes() == b[0].tobytes()
+            assert np.float32(a[1]).tobytes() == np.float32(b[1]).tobytes()
+            assert np.float32(a[2]).tobytes() == np.float32(b[2]).tobytes()
+    E.close()
+
+
 @pytest.mark.parametrize("name", ["g2_n128", "g7_n224", "g19_n200", "g20_n256", "g9_n35_odd", "g18_n50", "g1_n48"])
 def test_device_particle_precompute(name):
     """sum_RefMap / sumsquare_RefMap (same float summation order: bitwise) and the particle r2c on the device against
