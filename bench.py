@@ -55,6 +55,9 @@ def parse_args():
     ap.add_argument("--write-angles", type=int, nargs="?", const=10, default=0, metavar="K",
                     help="WRITE_PROB_ANGLES K: keep the per-orientation table (on the device, sharded) and select the K "
                          "best orientations per particle")
+    ap.add_argument("--direct", action="store_true",
+                    help="BASELINE config 4: cross-correlation as a sliding window in real space (BIOEM_CC_DIRECT=1; "
+                         "images up to 160 pixels, e.g. --pixels 128) instead of the transform path")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-orientations", type=int, default=64, help="orientations of the CPU-baseline sample")
     ap.add_argument("--cpu-repeats", type=int, default=3)
@@ -193,6 +196,8 @@ def cpu_baseline(W, n_orient, n_threads, repeats):
 
 def main():
     args = parse_args()
+    if args.direct:
+        os.environ["BIOEM_CC_DIRECT"] = "1"  # read by bioem_hip_create; inherited by self-launched ranks
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(args.gpus, [sys.executable, os.path.abspath(__file__)] + sys.argv[1:]))
     t_start = time.perf_counter()
@@ -340,7 +345,7 @@ def main():
                                                       (", WRITE_PROB_ANGLES %d" % K) if K else ""),
                    "pixels": W.N, "particles": W.nP, "orientations_per_gpu": W.nOrient, "ctf": W.nCTF,
                    "displacements": int(W.pd.NtotDisp), "orientation_list": "seeded uniform random quaternions",
-                   "fast_path": bool(E.fast_path), "parallelism": "orientation blocks x%d, one RCCL all-gather + "
+                   "fast_path": bool(E.fast_path), "cross_correlation": "direct (real-space sliding window)" if args.direct else "transform", "parallelism": "orientation blocks x%d, one RCCL all-gather + "
                    "log-sum-exp fold" % world},
     }
     # ---- roofline of the dominant kernel: VALU issue (the kernel is instruction-issue bound, not HBM bound) ----

@@ -4,10 +4,15 @@
 // Hot path (replaces bioem_cuda::compareRefMaps + cuFFT, /root/reference/bioem_cuda.cu:527-684, and the
 // host-side createProjection / createConvolutedProjectionMap, /root/reference/bioem.cpp:1604-1923):
 //
-//   prep_kernels.hpp     k_project        model points -> real-space projection (double atomics), one launch per batch
-//                        k_dft_rows/cols  r2c of the projections (exact DFT, double accumulation; off the critical path)
+//   prep_kernels.hpp     k_project_coords, k_project_bands  model points -> real-space projection: one record per
+//                          (orientation, point), bands of map rows in LDS (ds_add_f64), one store; k_project (global
+//                          double atomics) beyond 426 pixels
 //                        k_convolve       proj * conj(CTF) -> conv spectra in the comparison layout, sumC, Parseval terms
 //                        k_parseval_ordered  sumsquareC: the reference's sequential float sum, four chains per wave
+//                        k_convolve_sums  the two in one kernel (64 particles or fewer)
+//                        k_dft_rows/cols  r2c by exact DFT on the vector units (images beyond 304 pixels)
+//   dft_mfma.hpp         k_dft_rows_mfma / k_dft_cols_mfma  r2c of the projections and particle maps: the same exact DFT
+//                          (double accumulation) as v_mfma_f64_16x16x4_f64 products
 //                        k_reorder, k_map_sums: particle-side precompute
 //   compare_fast.hpp     k_compare_fast   windows of at most 21 rows; one WAVE per (particle, orientation*CTF) comparison:
 //                          spectrum product -> pruned inverse 2-D transform -> displacement-window log posterior
@@ -25,6 +30,8 @@
 //   compare_rows.hpp     k_compare_oddfft / k_compare_rows  odd image sizes: register FFT of odd length (3..25) over the
 //                          reference layout, or direct column sums when N has no factor 3 or 5
 //   compare_generic.hpp  k_compare_generic  same maths by direct pruned DFT (irregular wide displacement sets, N < 8)
+//   compare_direct.hpp   k_c2r_cols/rows, k_compare_direct  BIOEM_CC_DIRECT=1 (BASELINE config 4): the cross-correlation as a
+//                          sliding window in real space on the f32 matrix cores, no transform of the product
 //   window_tiles.hpp     k_phase_shift, k_merge_tiles  wide windows no kernel covers: tiles of a window kernel
 //   kernel_select.hpp    kernel table, k_compare_wide2 rules, plan_kernels: which kernel runs which shape
 //   posterior.hpp        calc_logpro / calProb semantics (bioem_algorithm.h:18-142)
@@ -138,6 +145,10 @@ struct bioem_hip_ctx
   float NormDen = 0, pixelSize = 0;
   int shiftX = 0, shiftY = 0;
   int iradMax = 0; // widest sphere footprint of the model, pixels (k_project_bands)
+  // BIOEM_CC_DIRECT=1 (BASELINE config 4): real-space particles, real-space conv maps of a launch, column pass of the c2r
+  bool direct = false;
+  float *dMapsReal = nullptr, *dConvReal = nullptr;
+  double2 *dDirectZ = nullptr;
   int nCU = 256;   // compute units of the device: size of the resident grids of the preparation kernels
   float4 *dAngles = nullptr;
   int nAnglesUp = 0, isQuat = 1;
@@ -223,6 +234,7 @@ struct bioem_hip_ctx
 #include "compare_fastm.hpp"
 #include "compare_generic.hpp"
 #include "compare_rows.hpp"
+#include "compare_direct.hpp"
 #include "kernel_select.hpp"
 #include "fold_kernels.hpp"
 #include "window_tiles.hpp"
@@ -337,7 +349,20 @@ int launch_compare_fold(bioem_hip_ctx *h, const BatchBuf &bb, int nOC, int orien
   // {t2, prior} of every row of the launch, once per row instead of once per comparison and lane
   hipLaunchKernelGGL(k_posterior_consts, dim3((nOC + 63) / 64), dim3(64), 0, h->stream, bb.params, h->pd, bb.postc, nOC);
   HIP_CHECK(h, hipEventRecord(e0, h->stream));
-  if (h->wide2)
+  if (h->direct)
+  {
+    CompareArgs ad = a;
+    ad.gs = h->pd.GridSpaceCenter;
+    ad.maxD = h->pd.maxDisplaceCenter;
+    hipLaunchKernelGGL(k_c2r_cols, dim3(h->H, nOC), dim3(128), sizeof(double2) * h->N, h->stream, bb.conv, h->N, h->H,
+                       h->fast, h->N1, h->dTwD, h->dDirectZ);
+    hipLaunchKernelGGL(k_c2r_rows, dim3(h->N, nOC), dim3(128), sizeof(double2) * h->H, h->stream, h->dDirectZ, h->N,
+                       h->H, h->dTwD, h->dConvReal);
+    const dim3 gridd((unsigned) ((size_t) nOC * ((h->nMaps + 31) / 32)));
+    hipLaunchKernelGGL(k_compare_direct<6>, gridd, dim3(256), direct_lds_bytes(h->N), h->stream, ad, h->dConvReal,
+                       h->dMapsReal);
+  }
+  else if (h->wide2)
   {
     CompareArgs aw = a;
     aw.twk = h->dTwk2;
@@ -878,6 +903,24 @@ static int create_impl(bioem_hip_handle *out, int device, const bioem_hip_param_
   HIP_CHECK(h, hipMalloc(&h->dParams, sizeof(bioem_hip_param5) * h->maxOC));
   HIP_CHECK(h, hipMalloc(&h->dPostC, sizeof(double2) * h->maxOC));
   HIP_CHECK(h, hipMalloc(&h->dPartials, sizeof(Partial) * (size_t) nMaps * h->maxOC));
+  if (const char *de = getenv("BIOEM_CC_DIRECT"))
+    h->direct = atoi(de) != 0;
+  if (h->direct)
+  { // compare_direct.hpp: the sliding-window evaluation of the same cross-correlation values
+    const int gsd = pd->GridSpaceCenter;
+    if (N > kDirectMaxN || gsd < 1 || maxD % gsd != 0 || 2 * (maxD / gsd) + 1 > 24 || h->tileT)
+    {
+      h->err = "BIOEM_CC_DIRECT: the direct cross-correlation takes images up to 160 pixels and regular windows of at "
+               "most 24 offsets per axis";
+      return 2;
+    }
+    HIP_CHECK(h, hipMalloc(&h->dMapsReal, sizeof(float) * (size_t) nMaps * N * N));
+    HIP_CHECK(h, hipMemset(h->dMapsReal, 0, sizeof(float) * (size_t) nMaps * N * N));
+    HIP_CHECK(h, hipMalloc(&h->dConvReal, sizeof(float) * (size_t) h->maxOC * N * N));
+    HIP_CHECK(h, hipMalloc(&h->dDirectZ, sizeof(double2) * (size_t) h->maxOC * M));
+    HIP_CHECK(h, hipFuncSetAttribute(reinterpret_cast<const void *>(k_compare_direct<6>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int) direct_lds_bytes(N)));
+  }
   if (h->nyq)
     HIP_CHECK(h, hipMalloc(&h->dTnyq, sizeof(float) * (size_t) nMaps * h->maxOC * (2 * h->winD + 1)));
   if (h->tileT)
@@ -1034,7 +1077,8 @@ int bioem_hip_destroy(bioem_hip_handle h)
                   h->dScratch, h->dConv,    h->dParams,   h->dPartials, h->dProb,
                   h->dProjReal2, h->dTempDen2, h->dRowSpec2, h->dSpecRef2, h->dScratch2, h->dConv2, h->dParams2,
                   h->dTnyq, h->dTwNyq, h->dPartTiles, h->dConvShift, h->dDispLocal, h->dRankOfRow, h->dTileCenter, h->dTileValid,
-                  h->dCand, h->dSend, h->dRecv, h->dMerged, h->dTwk2, h->dPostC, h->dPostC2};
+                  h->dCand, h->dSend, h->dRecv, h->dMerged, h->dTwk2, h->dPostC, h->dPostC2,
+                  h->dMapsReal, h->dConvReal, h->dDirectZ};
   for (void *p : ptrs)
     if (p)
       hipFree(p);
@@ -1060,6 +1104,11 @@ int bioem_hip_destroy(bioem_hip_handle h)
 int bioem_hip_upload_particles(bioem_hip_handle h, const float *refFFT, const float *sum, const float *sumsq)
 {
   HIP_CHECK(h, hipSetDevice(h->device));
+  if (h->direct)
+  {
+    h->err = "BIOEM_CC_DIRECT needs the particle images: bioem_hip_upload_particle_maps";
+    return 2;
+  }
   const size_t M = (size_t) h->M;
   HIP_CHECK(h, hipMemcpyAsync(h->dSumRef, sum, sizeof(float) * h->nMaps, hipMemcpyHostToDevice, h->stream));
   HIP_CHECK(h, hipMemcpyAsync(h->dSumsqRef, sumsq, sizeof(float) * h->nMaps, hipMemcpyHostToDevice, h->stream));
@@ -1090,6 +1139,9 @@ int bioem_hip_upload_particle_maps(bioem_hip_handle h, const float *maps)
                                 hipMemcpyHostToDevice, h->stream));
     hipLaunchKernelGGL(k_map_sums, dim3(n), dim3(256), 0, h->stream, dMaps, N * N, h->dSumRef + b, h->dSumsqRef + b);
     HIP_CHECK(h, hipGetLastError());
+    if (h->direct)
+      HIP_CHECK(h, hipMemcpyAsync(h->dMapsReal + (size_t) b * N * N, dMaps, sizeof(float) * (size_t) n * N * N,
+                                  hipMemcpyDeviceToDevice, h->stream));
     if (run_r2c(h, batch_buf(h, 0), h->stream, nullptr, dMaps, n))
     {
       hipFree(dMaps);
@@ -1263,7 +1315,9 @@ int bioem_hip_project_convolve_compare_ctf(bioem_hip_handle h, int iOrientBegin,
   // two-slot pipeline: projection + convolution of batch b+1 run on prepStream while batch b is compared
   // orientations per batch: the handle's capacity, but at least six batches per call where that leaves 64 or more per
   // batch -- the preparation of batch b+1 hides behind the comparison of batch b, the first batch's does not
-  // (20 particles x 2 304 orientations in 3 batches of 1 060: 11.5 ms per pass, a third of it the exposed first batch)
+  // (20 particles x 2 304 orientations in 3 batches of 1 060: 11.5 ms per pass, a third of it the exposed first batch;
+  // a ramp -- first batches a quarter and a half of the rest -- was measured too: 8.9 against 8.5 ms, more launches
+  // cost more than the shorter exposed preparation saves)
   // ... as long as a batch still compares ~32 000 pairs (a job of 23 000 pairs -- BASELINE config 1 -- is one batch:
   // 1.1 ms against 1.5 ms in six)
   const int perBatch = (int) std::min<long long>(h->OB, (32768 + (long long) nC * h->nMaps - 1) / ((long long) nC * h->nMaps));
@@ -1759,6 +1813,8 @@ const char *bioem_hip_kernel_name(bioem_hip_handle h)
 {
   if (!h)
     return "";
+  if (h->direct)
+    return "k_compare_direct";
   if (h->wide2)
     return "k_compare_wide2";
   if (h->fastm)
@@ -1774,7 +1830,9 @@ const char *bioem_hip_kernel_signature(bioem_hip_handle h)
     return "";
   static thread_local char buf[96];
   const char *nq = h->nyq ? "true" : "false";
-  if (h->wide2)
+  if (h->direct)
+    snprintf(buf, sizeof(buf), "k_compare_direct<6>");
+  else if (h->wide2)
     if (h->w2Halves == 2)
       snprintf(buf, sizeof(buf), h->w2NW == 8 ? "k_compare_wide2<%d, %d, %d, %s, 2, 8>" : "k_compare_wide2<%d, %d, %d, %s, 2>",
                2 * h->fast, h->w2NRW, h->w2NBLK, nq);

@@ -1059,6 +1059,54 @@ def test_config3_shape_ten_ctfs_two_shards():
     E.close()
 
 
+DIRECT_TOL = 2e-4  # relative, on the final log posterior: the sliding window adds 16 384 products in f32 per value
+
+
+@pytest.mark.parametrize("name", ["g10_n64", "g9_n35_odd", "g2_n128", "g1_n48", "g18_n50"])
+def test_direct_cross_correlation_against_oracle(name, monkeypatch):
+    """BIOEM_CC_DIRECT=1 (BASELINE config 4): the cross-correlation as a sliding window in real space (k_c2r_* +
+    k_compare_direct, no transform of the product) gives the oracle's posterior -- even, odd and 128^2 images,
+    ALGO 1 and 2, particles uploaded as images."""
+    case, S = setup_for(name)
+    monkeypatch.setenv("BIOEM_CC_DIRECT", "1")
+    for algo in case["algos"]:
+        try:
+            E = make_engine(S, algo, real_space_particles=True)
+        except RuntimeError as e:
+            if "BIOEM_CC_DIRECT" in str(e):
+                pytest.skip("window or image beyond the direct kernel: " + str(e))
+            raise
+        assert E.kernel_signature.startswith("k_compare_direct")
+        _, pmap, _ = run_native(E, S)
+        want, _ = S.run(algo)
+        for a, b in zip(pmap, want):
+            la, lb = S.final_logp(a), S.final_logp(b)
+            assert abs(la - lb) <= DIRECT_TOL * abs(lb), (la, lb)
+            assert (a["orient"], a["conv"]) == (b["orient"], b["conv"])
+        E.close()
+
+
+def test_config4_direct_kernel_equals_the_transform_path(monkeypatch):
+    """BASELINE config 4 at its own shape (128^2, +-10 px): both algorithms of the product on the same workload --
+    per particle the same best orientation / CTF / displacement and the same log posterior within DIRECT_TOL."""
+    from bioem_amd.synthetic import Workload
+    kw = dict(N=128, nP=96, nOrient=192, nEnv=2, maxD=10)
+    Wf = Workload(**kw)
+    assert Wf.engine.kernel_signature.startswith("k_compare_fast")
+    _, pf = run_workload(Wf, 0, Wf.nOrient)
+    monkeypatch.setenv("BIOEM_CC_DIRECT", "1")
+    Wd = Workload(**kw)
+    assert Wd.engine.kernel_signature == "k_compare_direct<6>"
+    rawd, pdm = run_workload(Wd, 0, Wd.nOrient)
+    rawd2, _ = run_workload(Wd, 0, Wd.nOrient)
+    assert rawd.tobytes() == rawd2.tobytes()
+    for f in ("orient", "conv", "cent_x", "cent_y"):
+        assert np.array_equal(pf[f], pdm[f]), f
+    lf = np.log(pf["Total"]) + pf["Constoadd"]
+    ld = np.log(pdm["Total"]) + pdm["Constoadd"]
+    assert np.abs(lf - ld).max() <= DIRECT_TOL * np.abs(lf).max()
+
+
 def test_config4_shape_against_direct_real_space_correlation():
     """BASELINE config 4 (FFT-free sliding-window algorithm, 128^2, 4 608 orientations) has no implementation in the
     reference; what it would compute is the SAME posterior from the real-space cross-correlation
