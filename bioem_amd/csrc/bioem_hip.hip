@@ -359,7 +359,7 @@ int launch_compare_fold(bioem_hip_ctx *h, const BatchBuf &bb, int nOC, int orien
     hipLaunchKernelGGL(k_c2r_rows, dim3(h->N, nOC), dim3(128), sizeof(double2) * h->H, h->stream, h->dDirectZ, h->N,
                        h->H, h->dTwD, h->dConvReal);
     const dim3 gridd((unsigned) ((size_t) nOC * ((h->nMaps + 31) / 32)));
-    hipLaunchKernelGGL(k_compare_direct<6>, gridd, dim3(256), direct_lds_bytes(h->N), h->stream, ad, h->dConvReal,
+    hipLaunchKernelGGL((k_compare_direct<3, 8>), gridd, dim3(512), direct_lds_bytes(h->N), h->stream, ad, h->dConvReal,
                        h->dMapsReal);
   }
   else if (h->wide2)
@@ -918,7 +918,7 @@ static int create_impl(bioem_hip_handle *out, int device, const bioem_hip_param_
     HIP_CHECK(h, hipMemset(h->dMapsReal, 0, sizeof(float) * (size_t) nMaps * N * N));
     HIP_CHECK(h, hipMalloc(&h->dConvReal, sizeof(float) * (size_t) h->maxOC * N * N));
     HIP_CHECK(h, hipMalloc(&h->dDirectZ, sizeof(double2) * (size_t) h->maxOC * M));
-    HIP_CHECK(h, hipFuncSetAttribute(reinterpret_cast<const void *>(k_compare_direct<6>),
+    HIP_CHECK(h, hipFuncSetAttribute(reinterpret_cast<const void *>(k_compare_direct<3, 8>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int) direct_lds_bytes(N)));
   }
   if (h->nyq)
@@ -1831,7 +1831,7 @@ const char *bioem_hip_kernel_signature(bioem_hip_handle h)
   static thread_local char buf[96];
   const char *nq = h->nyq ? "true" : "false";
   if (h->direct)
-    snprintf(buf, sizeof(buf), "k_compare_direct<6>");
+    snprintf(buf, sizeof(buf), "k_compare_direct<3, 8>");
   else if (h->wide2)
     if (h->w2Halves == 2)
       snprintf(buf, sizeof(buf), h->w2NW == 8 ? "k_compare_wide2<%d, %d, %d, %s, 2, 8>" : "k_compare_wide2<%d, %d, %d, %s, 2>",

@@ -9,18 +9,18 @@
 //                             unnormalised (so that posterior_batch divides by N^2 exactly as on the transform path):
 //                             FFTW's rdft2 c2r convention, exact DFT in double (inverse along x for the H stored
 //                             columns, then per row the half-complex inverse along y that ignores Im of column 0 and N/2)
-//   k_compare_direct<NDXW>    one block per (conv map, 32 particles): the conv map sits in LDS, the particles' rows
+//   k_compare_direct<NDXW, NWV>  one block of NWV waves per (conv map, 32 particles): the conv map sits in LDS, the particles' rows
 //                             stream through it.  For a window row offset dx the 2-D sum is a matrix product per image
 //                             row x:  out[dy][p] += A_x+dx[dy][y] * B_x[y][p],  A = the Toeplitz matrix of the conv row
 //                             (read from LDS with the column offset of the lane), B = row x of 32 particles.
 //                             v_mfma_f32_32x32x2_f32 (exact f32 products, f32 accumulation): M = 32 window columns,
-//                             N = 32 particles, K = 2 pixels per instruction.  Each of the four waves owns NDXW window
-//                             rows (its accumulators), all share B.  Then the log posterior of every displacement
+//                             N = 32 particles, K = 2 pixels per instruction.  Each wave owns NDXW window rows (its
+//                             accumulators), all share B.  Then the log posterior of every displacement
 //                             (posterior_batch) and the block's log-sum-exp partial per particle.
 // Cost: N^2 (2 maxD / gs + 1) * 32 / 2 matrix instructions per 32 comparisons = 21 x 16 384 FMAs per comparison at 128^2
 // +-10 px with the 21 -> 32 padding of M on top: the matrix pipe bounds it at ~7 M comparisons/s, a twentieth of the
-// transform path.  Images up to 160 pixels (the conv map must fit LDS), windows up to 24 offsets per axis (NDXW = 6
-// window rows per wave; eight make the compiler index the accumulators through scratch).
+// transform path.  Images up to 160 pixels (the conv map must fit LDS), windows up to 24 offsets per axis (eight waves
+// of three window rows each: 3.5 M comparisons/s at 128^2 +-10 px, 56 % of the matrix-pipe rate).
 #ifndef BIOEM_COMPARE_DIRECT_HPP
 #define BIOEM_COMPARE_DIRECT_HPP
 
@@ -111,11 +111,11 @@ __device__ __forceinline__ void lsef_merge(LseF &L, float m2, double s2, int id2
 inline size_t direct_lds_bytes(int N)
 {
   return sizeof(float) * ((size_t) N * N + 2 * 32 * (size_t) (N + 1)) + 64 * sizeof(double2) + 32 * sizeof(int) +
-         4 * 32 * (sizeof(double) + 3 * sizeof(float)) + 64;
+         8 * 32 * (sizeof(double) + 3 * sizeof(float)) + 64;
 }
 
-template <int NDXW>
-__global__ __launch_bounds__(256, 1) void k_compare_direct(const CompareArgs a, const float *__restrict__ convReal,
+template <int NDXW, int NWV>
+__global__ __launch_bounds__(64 * NWV, NWV / 4) void k_compare_direct(const CompareArgs a, const float *__restrict__ convReal,
                                                             const float *__restrict__ maps)
 {
   extern __shared__ __align__(16) unsigned char smem[];
@@ -125,10 +125,10 @@ __global__ __launch_bounds__(256, 1) void k_compare_direct(const CompareArgs a, 
   float *Bt = convS + (size_t) N * N;                                 // [2][32][BS]
   double2 *ltab = reinterpret_cast<double2 *>(Bt + 2 * 32 * BS + ((4 - ((2 * 32 * BS + N * N) & 3)) & 3)); // 64, 16-byte aligned
   int *rankW = reinterpret_cast<int *>(ltab + 64);                    // 32
-  double *mS = reinterpret_cast<double *>(rankW + 32);                // [4][32] partial sums
-  float *mM = reinterpret_cast<float *>(mS + 4 * 32);                 // [4][32] maxima
-  int *mI = reinterpret_cast<int *>(mM + 4 * 32);                     // [4][32] ids
-  float *mV = reinterpret_cast<float *>(mI + 4 * 32);                 // [4][32] values
+  double *mS = reinterpret_cast<double *>(rankW + 32);                // [NWV][32] partial sums
+  float *mM = reinterpret_cast<float *>(mS + NWV * 32);               // [NWV][32] maxima
+  int *mI = reinterpret_cast<int *>(mM + NWV * 32);                   // [NWV][32] ids
+  float *mV = reinterpret_cast<float *>(mI + NWV * 32);               // [NWV][32] values
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6));
   const int j = lane & 31, kh = lane >> 5;
   const int nPG = (a.nMaps + 31) >> 5;
@@ -149,16 +149,32 @@ __global__ __launch_bounds__(256, 1) void k_compare_direct(const CompareArgs a, 
     if (m >= 0 && m < 32)
       rankW[m] = t;
   }
-  // row x of the 32 particles -> Bt[buf][particle][y]
-  auto load_rows = [&](int x, int buf) {
-    for (int e = threadIdx.x; e < 32 * N; e += blockDim.x)
+  // row x of the 32 particles -> registers (fetch) -> Bt[buf][particle][y] (stash): the loads of row x + 1 fly while row
+  // x is multiplied
+  constexpr int PRE = (32 * kDirectMaxN + 64 * NWV - 1) / (64 * NWV);
+  float pre[PRE];
+  auto fetch = [&](int x) {
+#pragma unroll
+    for (int u = 0; u < PRE; u++)
     {
+      const int e = (int) threadIdx.x + u * 64 * NWV;
       const int jj = e / N, y = e - jj * N;
       const int p = p0 + jj;
-      Bt[(buf * 32 + jj) * BS + y] = p < a.nMaps ? maps[((size_t) p * N + x) * N + y] : 0.f;
+      pre[u] = (jj < 32 && p < a.nMaps) ? maps[((size_t) p * N + x) * N + y] : 0.f;
     }
   };
-  load_rows(0, 0);
+  auto stash = [&](int buf) {
+#pragma unroll
+    for (int u = 0; u < PRE; u++)
+    {
+      const int e = (int) threadIdx.x + u * 64 * NWV;
+      const int jj = e / N, y = e - jj * N;
+      if (jj < 32)
+        Bt[(buf * 32 + jj) * BS + y] = pre[u];
+    }
+  };
+  fetch(0);
+  stash(0);
 
   floatx16 D[NDXW];
 #pragma unroll
@@ -177,7 +193,7 @@ __global__ __launch_bounds__(256, 1) void k_compare_direct(const CompareArgs a, 
   {
     __syncthreads(); // Bt[x & 1] is complete, Bt[~x & 1] is free
     if (x + 1 < N)
-      load_rows(x + 1, (x + 1) & 1);
+      fetch(x + 1);
     const float *Bx = Bt + ((x & 1) * 32 + j) * BS;
     for (int s0 = 0; s0 < steps; s0 += KC)
     {
@@ -192,6 +208,8 @@ __global__ __launch_bounds__(256, 1) void k_compare_direct(const CompareArgs a, 
       for (int q = 0; q < NDXW; q++)
       {
         const int mx = wave * NDXW + q; // window row of this wave's accumulator q
+        if (mx >= nd)
+          continue;
         int xr = (x + (mx - mD) * gs) % N;
         xr = xr < 0 ? xr + N : xr;
         const float *Ar = convS + xr * N;
@@ -208,6 +226,8 @@ __global__ __launch_bounds__(256, 1) void k_compare_direct(const CompareArgs a, 
         }
       }
     }
+    if (x + 1 < N)
+      stash((x + 1) & 1);
   }
 
   // D[q][i]: window row mx = wave NDXW + q, window column m = 8 (i / 4) + 4 kh + i % 4, particle p0 + j
@@ -257,7 +277,7 @@ __global__ __launch_bounds__(256, 1) void k_compare_direct(const CompareArgs a, 
   __syncthreads();
   if (wave == 0 && lane < 32 && pvalid)
   {
-    for (int w = 1; w < 4; w++)
+    for (int w = 1; w < NWV; w++)
       lsef_merge(L, mM[w * 32 + j], mS[w * 32 + j], mI[w * 32 + j], mV[w * 32 + j]);
     Partial r;
     r.sumExp = L.s;

@@ -1096,7 +1096,7 @@ def test_config4_direct_kernel_equals_the_transform_path(monkeypatch):
     _, pf = run_workload(Wf, 0, Wf.nOrient)
     monkeypatch.setenv("BIOEM_CC_DIRECT", "1")
     Wd = Workload(**kw)
-    assert Wd.engine.kernel_signature == "k_compare_direct<6>"
+    assert Wd.engine.kernel_signature == "k_compare_direct<3, 8>"
     rawd, pdm = run_workload(Wd, 0, Wd.nOrient)
     rawd2, _ = run_workload(Wd, 0, Wd.nOrient)
     assert rawd.tobytes() == rawd2.tobytes()
