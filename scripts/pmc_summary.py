@@ -41,7 +41,8 @@ def read_pass(d):
     files = glob.glob(os.path.join(d, "*", "*counter_collection.csv")) + glob.glob(os.path.join(d, "*counter_collection.csv"))
     if not files:
         return None, None, None
-    rows = list(csv.DictReader(open(files[0])))
+    files.sort(key=os.path.getmtime)  # gpurun merges every call's files into gpurun_out/: take the latest run's
+    rows = list(csv.DictReader(open(files[-1])))
     kname = dominant_kernel(rows)
     vals, durs = {}, []
     seen = set()
@@ -79,6 +80,8 @@ def main():
     st = glob.glob(os.path.join(base, "stats", "*", "*kernel_stats.csv")) + glob.glob(os.path.join(base, "stats", "*kernel_stats.csv"))
     kstats = None
     if st:
+        st.sort(key=os.path.getmtime)
+        st = st[-1:]
         shutil.copy(st[0], "profiles/%s_kernel_stats.csv" % tag)
         rows = list(csv.DictReader(open(st[0])))
         cmp_rows = [r for r in rows if "k_compare" in r["Name"]]
