@@ -9,8 +9,8 @@
 //                             unnormalised (so that posterior_batch divides by N^2 exactly as on the transform path):
 //                             FFTW's rdft2 c2r convention, exact DFT in double (inverse along x for the H stored
 //                             columns, then per row the half-complex inverse along y that ignores Im of column 0 and N/2)
-//   k_compare_direct<NDXW, NWV>  one block of NWV waves per (conv map, 32 particles): the conv map sits in LDS, the particles' rows
-//                             stream through it.  For a window row offset dx the 2-D sum is a matrix product per image
+//   k_compare_direct<NDXW, NWV>  one block of NWV waves per (conv map, 32 particles): the conv map sits in LDS, the
+//                             particles' rows stream through it.  For a window row offset dx the 2-D sum is a matrix product per image
 //                             row x:  out[dy][p] += A_x+dx[dy][y] * B_x[y][p],  A = the Toeplitz matrix of the conv row
 //                             (read from LDS with the column offset of the lane), B = row x of 32 particles.
 //                             v_mfma_f32_32x32x2_f32 (exact f32 products, f32 accumulation): M = 32 window columns,
@@ -60,7 +60,8 @@ __global__ void k_c2r_cols(const float2 *__restrict__ conv, int N, int H, int fa
   }
 }
 
-// real[oc][x][y] = Re Z[x][0] + (-1)^y Re Z[x][N/2] (even N) + 2 sum_{0 < ky < N/2 (or <= (N-1)/2)} Re(Z[x][ky] e^{+2 pi i ky y/N})
+// real[oc][x][y] = Re Z[x][0] + (-1)^y Re Z[x][N/2] (even N)
+//                   + 2 sum_{0 < ky < N/2 (odd N: <= (N-1)/2)} Re(Z[x][ky] e^{+2 pi i ky y/N});  block = (x, oc), thread = y
 __global__ void k_c2r_rows(const double2 *__restrict__ Z, int N, int H, const double2 *__restrict__ twD,
                            float *__restrict__ real)
 {
@@ -115,15 +116,16 @@ inline size_t direct_lds_bytes(int N)
 }
 
 template <int NDXW, int NWV>
-__global__ __launch_bounds__(64 * NWV, NWV / 4) void k_compare_direct(const CompareArgs a, const float *__restrict__ convReal,
-                                                            const float *__restrict__ maps)
+__global__ __launch_bounds__(64 * NWV, NWV / 4) void
+k_compare_direct(const CompareArgs a, const float *__restrict__ convReal, const float *__restrict__ maps)
 {
   extern __shared__ __align__(16) unsigned char smem[];
   const int N = a.N;
   const int BS = N + 1; // row stride of the particle tile: the 32 lanes of a read hit 32 banks
   float *convS = reinterpret_cast<float *>(smem);                     // [N][N]
   float *Bt = convS + (size_t) N * N;                                 // [2][32][BS]
-  double2 *ltab = reinterpret_cast<double2 *>(Bt + 2 * 32 * BS + ((4 - ((2 * 32 * BS + N * N) & 3)) & 3)); // 64, 16-byte aligned
+  const int padF = (4 - ((2 * 32 * BS + N * N) & 3)) & 3; // floats up to the next 16-byte boundary
+  double2 *ltab = reinterpret_cast<double2 *>(Bt + 2 * 32 * BS + padF); // 64
   int *rankW = reinterpret_cast<int *>(ltab + 64);                    // 32
   double *mS = reinterpret_cast<double *>(rankW + 32);                // [NWV][32] partial sums
   float *mM = reinterpret_cast<float *>(mS + NWV * 32);               // [NWV][32] maxima

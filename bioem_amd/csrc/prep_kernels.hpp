@@ -215,90 +215,90 @@ __global__ __launch_bounds__(256) void k_project_bands(const ProjectRecord *__re
   // a resident grid walks the (orientation, band) units: launching a 50 KiB-LDS block costs more than one short unit
   for (int unit = blockIdx.x; unit < nO * nBands; unit += gridDim.x)
   {
-  const int ob = unit / nBands;
-  const int r0 = (unit - ob * nBands) * TR, r1 = min(N, r0 + TR);
-  const ProjectRecord *C = coords + (size_t) ob * nPts;
-  __syncthreads(); // the previous band is stored
-  for (int e = threadIdx.x; e < (r1 - r0) * N; e += blockDim.x)
-    band[e] = 0.;
-  double td = 0.;
-  // 2 048 records per round sit in registers (one wait for global memory), listed and splatted 512 at a time
-  for (int n00 = 0; n00 < nPts; n00 += 4 * kProjectList)
-  {
-    ProjectRecord rec[8];
-#pragma unroll
-    for (int u = 0; u < 8; u++)
+    const int ob = unit / nBands;
+    const int r0 = (unit - ob * nBands) * TR, r1 = min(N, r0 + TR);
+    const ProjectRecord *C = coords + (size_t) ob * nPts;
+    __syncthreads(); // the previous band is stored
+    for (int e = threadIdx.x; e < (r1 - r0) * N; e += blockDim.x)
+      band[e] = 0.;
+    double td = 0.;
+    // 2 048 records per round sit in registers (one wait for global memory), listed and splatted 512 at a time
+    for (int n00 = 0; n00 < nPts; n00 += 4 * kProjectList)
     {
-      const int n = n00 + u * 256 + threadIdx.x;
-      rec[u] = C[min(n, nPts - 1)];
-      rec[u].ij = n < nPts ? rec[u].ij : -1;
-    }
+      ProjectRecord rec[8];
 #pragma unroll
-    for (int g = 0; g < 4; g++)
-    {
-      if (n00 + g * kProjectList >= nPts)
-        break;
-      if (threadIdx.x == 0)
-        cnt = 0;
-      __syncthreads();
-#pragma unroll
-      for (int u = 2 * g; u < 2 * g + 2; u++)
+      for (int u = 0; u < 8; u++)
       {
-        const ProjectRecord r = rec[u];
-        const int i = r.ij >> 16;
-        if (r.ij >= 0 && i + r.irad >= r0 && i - r.irad < r1)
-          list[atomicAdd(&cnt, 1)] = r;
+        const int n = n00 + u * 256 + threadIdx.x;
+        rec[u] = C[min(n, nPts - 1)];
+        rec[u].ij = n < nPts ? rec[u].ij : -1;
       }
-      __syncthreads();
-      const int items = cnt * S;
-      for (int it = threadIdx.x; it < items; it += blockDim.x)
+#pragma unroll
+      for (int g = 0; g < 4; g++)
       {
-        const int en = it / S, dj = it - en * S - iradMax;
-        const ProjectRecord q = list[en];
-        const int i = q.ij >> 16, j = q.ij & 0xffff;
-        const float radius = q.radius, density = q.density;
-        if (q.irad == 0)
-        { // a point: bioem.cpp:1700-1712
-          if (dj == 0)
-          {
-            atomicAdd(&band[(i - r0) * N + j], (double) density);
-            td += (double) density;
-          }
-          continue;
-        }
-        if (dj < -q.irad || dj > q.irad)
-          continue;
-        const float rad2 = radius * radius;
-        const int jj = j + dj;
-        for (int ii = max(i - q.irad, r0); ii < min(i + q.irad + 1, r1); ii++)
+        if (n00 + g * kProjectList >= nPts)
+          break;
+        if (threadIdx.x == 0)
+          cnt = 0;
+        __syncthreads();
+#pragma unroll
+        for (int u = 2 * g; u < 2 * g + 2; u++)
         {
-          const float dist = ((float) (ii - i) * (ii - i) + (jj - j) * (jj - j)) * pixelSize * pixelSize;
-          if (dist < rad2)
+          const ProjectRecord r = rec[u];
+          const int i = r.ij >> 16;
+          if (r.ij >= 0 && i + r.irad >= r0 && i - r.irad < r1)
+            list[atomicAdd(&cnt, 1)] = r;
+        }
+        __syncthreads();
+        const int items = cnt * S;
+        for (int it = threadIdx.x; it < items; it += blockDim.x)
+        {
+          const int en = it / S, dj = it - en * S - iradMax;
+          const ProjectRecord q = list[en];
+          const int i = q.ij >> 16, j = q.ij & 0xffff;
+          const float radius = q.radius, density = q.density;
+          if (q.irad == 0)
+          { // a point: bioem.cpp:1700-1712
+            if (dj == 0)
+            {
+              atomicAdd(&band[(i - r0) * N + j], (double) density);
+              td += (double) density;
+            }
+            continue;
+          }
+          if (dj < -q.irad || dj > q.irad)
+            continue;
+          const float rad2 = radius * radius;
+          const int jj = j + dj;
+          for (int ii = max(i - q.irad, r0); ii < min(i + q.irad + 1, r1); ii++)
           {
-            const double w = (double) (pixelSize * pixelSize * 2 * sqrtf(rad2 - dist) * density * 3) /
-                             (4 * M_PI * radius * rad2);
-            atomicAdd(&band[(ii - r0) * N + jj], w);
-            td += w;
+            const float dist = ((float) (ii - i) * (ii - i) + (jj - j) * (jj - j)) * pixelSize * pixelSize;
+            if (dist < rad2)
+            {
+              const double w = (double) (pixelSize * pixelSize * 2 * sqrtf(rad2 - dist) * density * 3) /
+                               (4 * M_PI * radius * rad2);
+              atomicAdd(&band[(ii - r0) * N + jj], w);
+              td += w;
+            }
           }
         }
+        __syncthreads(); // the list is rewritten by the next points
       }
-      __syncthreads(); // the list is rewritten by the next points
     }
-  }
-  for (int o = 32; o > 0; o >>= 1)
-    td += __shfl_down(td, o);
-  if ((threadIdx.x & 63) == 0)
-    red[threadIdx.x >> 6] = td;
-  __syncthreads(); // also: every splat of this band is done
-  if (threadIdx.x == 0)
-  {
-    const double t = (red[0] + red[1]) + (red[2] + red[3]);
-    if (t != 0.)
-      atomicAdd(&tempden[ob], t);
-  }
-  double *map = proj + (size_t) ob * N * N + (size_t) r0 * N;
-  for (int e = threadIdx.x; e < (r1 - r0) * N; e += blockDim.x)
-    map[e] = band[e];
+    for (int o = 32; o > 0; o >>= 1)
+      td += __shfl_down(td, o);
+    if ((threadIdx.x & 63) == 0)
+      red[threadIdx.x >> 6] = td;
+    __syncthreads(); // also: every splat of this band is done
+    if (threadIdx.x == 0)
+    {
+      const double t = (red[0] + red[1]) + (red[2] + red[3]);
+      if (t != 0.)
+        atomicAdd(&tempden[ob], t);
+    }
+    double *map = proj + (size_t) ob * N * N + (size_t) r0 * N;
+    for (int e = threadIdx.x; e < (r1 - r0) * N; e += blockDim.x)
+      map[e] = band[e];
   }
 }
 
@@ -634,10 +634,9 @@ __device__ inline void lds_barrier()
 
 constexpr int kConvThreads = 1024; // one adding wave, fifteen producing waves: a tile costs them one round of loads
 
-__global__ __launch_bounds__(kConvThreads) void k_convolve_sums(const float2 *__restrict__ proj, const float2 *__restrict__ ctf,
-                                                        const float *__restrict__ ctfParam, int N, int H, int fast,
-                                                        int N1, int c0, int nC, float2 *__restrict__ conv,
-                                                        bioem_hip_param5 *__restrict__ params)
+__global__ __launch_bounds__(kConvThreads) void
+k_convolve_sums(const float2 *__restrict__ proj, const float2 *__restrict__ ctf, const float *__restrict__ ctfParam,
+                int N, int H, int fast, int N1, int c0, int nC, float2 *__restrict__ conv, bioem_hip_param5 *__restrict__ params)
 {
   __shared__ __align__(16) float terms[2][kConvCtfs][kConvStride];
   __shared__ float sC[kConvCtfs];
