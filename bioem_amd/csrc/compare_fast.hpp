@@ -267,13 +267,15 @@ __device__ __forceinline__ bool fast_block_pair(const CompareArgs &a, int &p, in
 // displacement rows so that each LDS twiddle read E[ky*dy] feeds nr accumulators; T is read two columns
 // at a time (ds_read_b128).  STATIC: nr == NR known at compile time (the +-10 px, grid 1 case).
 // NP = number of column pairs: 32 for a block, 1 for the Nyquist column parked in the pad columns 64/65.
+// npairs <= NP: column pairs that hold columns of the spectrum (the last block of a size like 224, 160 is not full; the
+// columns beyond are zeros whose terms leave every accumulator unchanged, so skipping them is bit-identical).
 template <int NR, bool STATIC, int NP, int TS>
 __device__ __forceinline__ void window_accumulate(const float2 *Tl, const float2 *twl, int N, int step, int idx0,
-                                                  const int (&rowoff)[NR], int nr, float (&acc)[NR])
+                                                  const int (&rowoff)[NR], int nr, float (&acc)[NR], int npairs = NP)
 {
   int idx = idx0;
 #pragma unroll 2
-  for (int kp = 0; kp < NP; kp++)
+  for (int kp = 0; kp < npairs; kp++)
   {
     const float2 w0 = twl[idx];
     idx += step;
@@ -545,10 +547,15 @@ __global__ __launch_bounds__(256, BIOEM_FAST_WAVES_PER_SIMD) void k_compare_fast
         Tl[d * TS + lane] = make_float2(Tr[d] * wgt, Ti[d] * wgt);
       WAVE_OR_BLOCK_SYNC();
       const int idx0 = (int) (((long long) (blk * 64) * step) % N);
+#if BIOEM_MASK_IDLE_COLUMNS
+      const int npairs = min(32, (H - blk * 64 + 1) >> 1); // columns of this block that exist, in pairs
+#else
+      const int npairs = 32;
+#endif
       if (is_static)
       {
         const int rowoff[NR] = {rowbase};
-        window_accumulate<NR, true, 32, TS>(Tl, twl, N, step, idx0, rowoff, nr, acc);
+        window_accumulate<NR, true, 32, TS>(Tl, twl, N, step, idx0, rowoff, nr, acc, npairs);
       }
       else
       {
@@ -556,7 +563,7 @@ __global__ __launch_bounds__(256, BIOEM_FAST_WAVES_PER_SIMD) void k_compare_fast
 #pragma unroll
         for (int r = 0; r < NR; r++)
           rowoff[r] = row_of(r);
-        window_accumulate<NR, false, 32, TS>(Tl, twl, N, step, idx0, rowoff, nr, acc);
+        window_accumulate<NR, false, 32, TS>(Tl, twl, N, step, idx0, rowoff, nr, acc, npairs);
       }
     }
   }

@@ -224,8 +224,10 @@ __global__ __launch_bounds__(256, 3) void k_compare_fastm(const CompareArgs a)
       if (ky0 < (NYQ ? H - 1 : H))
       {
         unsigned idx = (unsigned) (((long long) ky0 * stepn) % N);
-#pragma unroll
-        for (int kk = 0; kk < 32; kk++)
+        // columns of this half that exist (the rest hold zeros: their products leave D unchanged)
+        const int nk = min(32, (NYQ ? H - 1 : H) - ky0);
+#pragma unroll 8
+        for (int kk = 0; kk < nk; kk++)
         {
           const float av = Arow[kk];
           const float bv = Btab[idx + (idx >> 5)];

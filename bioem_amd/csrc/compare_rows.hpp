@@ -158,10 +158,11 @@ __global__ __launch_bounds__(256, (WD <= 10 ? 3 : 2)) void k_compare_rows(const 
       Tl[d * TS + lane] = make_float2(Tr[d] * wgt, Ti[d] * wgt);
     WAVE_OR_BLOCK_SYNC();
     const int idx0 = (int) (((long long) blk * 64 * step) % N);
+    const int npairs = min(32, (H - blk * 64 + 1) >> 1); // columns of this block that exist, in pairs
     if (is_static)
     {
       const int rowoff[NR] = {rowbase};
-      window_accumulate<NR, true, 32, TS>(Tl, twl, N, step, idx0, rowoff, nr, acc);
+      window_accumulate<NR, true, 32, TS>(Tl, twl, N, step, idx0, rowoff, nr, acc, npairs);
     }
     else
     {
@@ -169,7 +170,7 @@ __global__ __launch_bounds__(256, (WD <= 10 ? 3 : 2)) void k_compare_rows(const 
 #pragma unroll
       for (int r = 0; r < NR; r++)
         rowoff[r] = row_of(r);
-      window_accumulate<NR, false, 32, TS>(Tl, twl, N, step, idx0, rowoff, nr, acc);
+      window_accumulate<NR, false, 32, TS>(Tl, twl, N, step, idx0, rowoff, nr, acc, npairs);
     }
   }
 
@@ -374,10 +375,11 @@ __global__ __launch_bounds__(256, (WD <= 10 ? 3 : 2)) void k_compare_oddfft(cons
       Tl[d * TS + lane] = make_float2(Tr[d] * wgt, Ti[d] * wgt);
     WAVE_OR_BLOCK_SYNC();
     const int idx0 = (int) (((long long) blk * 64 * step) % N);
+    const int npairs = min(32, (H - blk * 64 + 1) >> 1); // columns of this block that exist, in pairs
     if (is_static)
     {
       const int rowoff[NR] = {rowbase};
-      window_accumulate<NR, true, 32, TS>(Tl, twl, N, step, idx0, rowoff, nr, acc);
+      window_accumulate<NR, true, 32, TS>(Tl, twl, N, step, idx0, rowoff, nr, acc, npairs);
     }
     else
     {
@@ -385,7 +387,7 @@ __global__ __launch_bounds__(256, (WD <= 10 ? 3 : 2)) void k_compare_oddfft(cons
 #pragma unroll
       for (int r = 0; r < NR; r++)
         rowoff[r] = row_of(r);
-      window_accumulate<NR, false, 32, TS>(Tl, twl, N, step, idx0, rowoff, nr, acc);
+      window_accumulate<NR, false, 32, TS>(Tl, twl, N, step, idx0, rowoff, nr, acc, npairs);
     }
   }
 
