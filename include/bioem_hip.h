@@ -89,7 +89,11 @@ int bioem_hip_device_count(void);
 
 /* Replaces bioem_cuda::deviceInit (bioem_cuda.cu:818-951): allocate device state for nMaps particles,
  * nAngles orientations, nCTF kernels.  algo = BIOEM_ALGO (1 or 2: displacement set + reduction
- * semantics of bioem_algorithm.h:144-198 / bioem.cpp:1461-1602).  device = HIP ordinal. */
+ * semantics of bioem_algorithm.h:144-198 / bioem.cpp:1461-1602).  device = HIP ordinal.
+ * Environment, read here: BIOEM_CC_DIRECT=1 makes the handle evaluate the cross-correlation of bioem.cpp:1435-1459 as
+ * a sliding window in real space instead of through the transform (BASELINE config 4; no counterpart in the
+ * reference, doc/index.rst:1658-1663): images up to 160 pixels, regular windows of at most 24 offsets per axis,
+ * particles through bioem_hip_upload_particle_maps; create fails with a message otherwise. */
 int bioem_hip_create(bioem_hip_handle *out, int device, const bioem_hip_param_device *pd, int nMaps, int nAngles,
                      int nCTF, int algo);
 /* Shard variant of bioem_hip_create for orientation-sharded runs (the reference's MPI blocks, bioem.cpp:748-753): this
