@@ -224,32 +224,17 @@ __global__ __launch_bounds__(256, 3) void k_compare_fastm(const CompareArgs a)
       if (ky0 < (NYQ ? H - 1 : H))
       {
         unsigned idx = (unsigned) (((long long) ky0 * stepn) % N);
-        // columns of this half that exist (the rest hold zeros: their products leave D unchanged).  The full half keeps
-        // its unrolled stream (immediate LDS offsets); a counted loop there costs 5-8 % at 200^2 / 240^2.
+        // columns of this half that exist (the rest hold zeros: their products leave D unchanged).  (A separate fully
+        // unrolled stream for full halves is another 1 % faster at 200^2 and spills two registers in <15, 10>.)
         const int nk = min(32, (NYQ ? H - 1 : H) - ky0);
-        if (nk == 32)
+#pragma unroll 8
+        for (int kk = 0; kk < nk; kk++)
         {
-#pragma unroll
-          for (int kk = 0; kk < 32; kk++)
-          {
-            const float av = Arow[kk];
-            const float bv = Btab[idx + (idx >> 5)];
-            D = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, D, 0, 0, 0);
-            idx += (unsigned) stepn;
-            idx = min(idx, idx - (unsigned) N); // idx < 2N: the wrapped difference is huge unless idx >= N
-          }
-        }
-        else
-        {
-#pragma unroll 4
-          for (int kk = 0; kk < nk; kk++)
-          {
-            const float av = Arow[kk];
-            const float bv = Btab[idx + (idx >> 5)];
-            D = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, D, 0, 0, 0);
-            idx += (unsigned) stepn;
-            idx = min(idx, idx - (unsigned) N);
-          }
+          const float av = Arow[kk];
+          const float bv = Btab[idx + (idx >> 5)];
+          D = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, D, 0, 0, 0);
+          idx += (unsigned) stepn;
+          idx = min(idx, idx - (unsigned) N); // idx < 2N: the wrapped difference is huge unless idx >= N
         }
       }
     }
