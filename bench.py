@@ -58,6 +58,10 @@ def parse_args():
     ap.add_argument("--direct", action="store_true",
                     help="BASELINE config 4: cross-correlation as a sliding window in real space (BIOEM_CC_DIRECT=1; "
                          "images up to 160 pixels, e.g. --pixels 128) instead of the transform path")
+    ap.add_argument("--max-seconds", type=float, default=480.0,
+                    help="wall-clock budget of the whole run (set-up + warm-up + timed steps + merge): after the first "
+                         "warm-up step the warm-up and step counts are trimmed, on every rank alike, so that the run "
+                         "ends inside it; the line reports steps_requested / steps (= run) and warmup_requested / warmup")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-orientations", type=int, default=64, help="orientations of the CPU-baseline sample")
     ap.add_argument("--cpu-repeats", type=int, default=3)
@@ -142,6 +146,35 @@ def self_launch(n, child_argv, poll_s=0.2, out=None):
                          "(%s):\n%s\n" % (r, n, c, path, tail))
         return c
     return 0
+
+
+def plan_steps(steps, warmup_left, step_s, elapsed_s, max_seconds, tail_s):
+    """Time budget (--max-seconds): how many of the remaining `warmup_left` warm-up steps and of the `steps` timed steps
+    still fit, given that one step took `step_s` and `elapsed_s` of the budget are gone; `tail_s` is kept for what
+    follows the timed region (merge, CPU baseline, parity leg).  Warm-up goes first, then timed steps; at least one timed
+    step always runs.  Pure function: every rank calls it with the same (max-reduced) numbers."""
+    if max_seconds is None or max_seconds <= 0 or step_s <= 0:
+        return warmup_left, steps
+    fit = int(max(0.0, max_seconds - elapsed_s - tail_s) / step_s)
+    fit = max(1, fit)
+    w = min(warmup_left, max(0, fit - steps))
+    return w, min(steps, max(1, fit - w))
+
+
+def shared_stack_path(shape):
+    """One particle stack per NODE for the N > 1 runs: rank 0 renders and leaves it in /dev/shm, the other ranks map it
+    (config 3: 2 GB once instead of 2 GB and a rendering pass per rank)."""
+    tag = "_".join(str(int(v)) for v in shape)
+    return "/dev/shm/bioem_bench_stack_%s_%s.npy" % (os.environ.get("MASTER_PORT", "0"), tag)
+
+
+def wait_for_file(path, timeout_s, poll_s=0.2):
+    t0 = time.time()
+    while not os.path.exists(path):
+        if time.time() - t0 > timeout_s:
+            return False
+        time.sleep(poll_s)
+    return True
 
 
 def cpu_model():
@@ -240,9 +273,26 @@ def main():
     # the global orientation list is `world` blocks of `orientations`; rank r owns block r; every rank renders the
     # same particle stack (from block 0, same seeds), i.e. the N = 1 workload's stack
     K = int(args.write_angles)
-    W = Workload(N=args.pixels, nP=args.particles, nOrient=args.orientations, device=gpu_index, nEnv=args.envelopes,
-                 nDefocus=args.defocus, maxD=args.max_displacement, grid=args.grid, write_angles=K, blocks=world,
-                 block=rank)
+    wl = dict(N=args.pixels, nP=args.particles, nOrient=args.orientations, device=gpu_index, nEnv=args.envelopes,
+              nDefocus=args.defocus, maxD=args.max_displacement, grid=args.grid, write_angles=K, blocks=world, block=rank)
+    stack_file = None
+    if world > 1 and os.access("/dev/shm", os.W_OK) and not os.environ.get("BIOEM_BENCH_RENDER_PER_RANK"):
+        stack_file = shared_stack_path((args.pixels, args.particles, args.orientations, args.envelopes, args.defocus))
+    if stack_file is None:
+        W = Workload(**wl)
+        stack_source = "rendered by this rank"
+    elif rank == 0:
+        W = Workload(**wl)
+        np.save(stack_file + ".tmp.npy", W.maps)
+        os.replace(stack_file + ".tmp.npy", stack_file)     # atomic: a waiting rank never sees a partial file
+        stack_source = "rendered by rank 0, shared through %s" % stack_file
+    else:
+        W = Workload(render=False, **wl)
+        if not wait_for_file(stack_file, float(os.environ.get("BIOEM_BENCH_RENDER_WAIT_S", "600"))):
+            raise RuntimeError("rank %d: the particle stack %s of rank 0 did not appear" % (rank, stack_file))
+        W.maps = np.load(stack_file, mmap_mode="r")
+        W.engine.upload_particle_maps(W.maps)
+        stack_source = "mapped from %s" % stack_file
     E = W.engine
     nMaps = W.nP
     numconst = 0.0
@@ -284,17 +334,44 @@ def main():
         if backend == "nccl":
             torch.cuda.synchronize()
         comm_setup_s = time.perf_counter() - tc
-    for _ in range(args.warmup):
+    def rank_max(x):
+        if world == 1:
+            return x
+        t = torch.tensor([x], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    # time budget (--max-seconds): the first executed step prices a step; warm-up, then timed steps are trimmed to fit
+    tail_s = 90.0 if (world == 1 and not args.no_cpu_baseline) else 10.0
+    warmup_run, steps_run = args.warmup, args.steps
+    if args.warmup > 0:
+        tp = time.perf_counter()
         one_step()
+        sync()
+        step_s = rank_max(time.perf_counter() - tp)
+        w_extra, steps_run = plan_steps(args.steps, args.warmup - 1, step_s, rank_max(time.perf_counter() - t_start),
+                                        args.max_seconds, tail_s)
+        for _ in range(w_extra):
+            one_step()
+        warmup_run = 1 + w_extra
     sync()
     E.reset_kernel_stats()
     merge_s[0] = 0.0
     setup_s = time.perf_counter() - t_start
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    done = 0
+    while done < steps_run:
         last = one_step()
+        done += 1
+        if args.warmup == 0 and done == 1 and steps_run > 1:
+            sync()          # no warm-up step priced a step: the first timed one does (one extra barrier in the region)
+            _, more = plan_steps(args.steps - 1, 0, rank_max(time.perf_counter() - t0),
+                                 rank_max(time.perf_counter() - t_start), args.max_seconds, tail_s)
+            steps_run = 1 + more
     sync()
     dt = time.perf_counter() - t0
+    steps_requested, warmup_requested = args.steps, args.warmup
+    args.steps, args.warmup = steps_run, warmup_run
     kms, launches, ncomp = E.kernel_stats()
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
@@ -327,6 +404,10 @@ def main():
         "n_gpus": world,
         "steps": args.steps,
         "warmup": args.warmup,
+        # --max-seconds: what was asked for; "steps" / "warmup" above are what ran (equal unless the budget trimmed them)
+        "steps_requested": steps_requested,
+        "warmup_requested": warmup_requested,
+        "max_seconds": args.max_seconds,
         "ms_per_step": 1e3 * dt / args.steps,
         # inside ms_per_step: this rank's share of it spent in the shard merge (D2H of the 40-byte entries, ONE
         # all-gather, host fold); outside: everything before the timed region (imports, particle rendering, uploads,
@@ -367,6 +448,12 @@ def main():
     rl["alg_TFLOPs_kernel"] = (ncomp * alg_flops / 1e12) / (kms / 1e3) if kms > 0 else None
     rl["fp32_vector_peak_TFLOPs"] = FP32_VECTOR_PEAK_TFLOPS
     rl["frac_of_fp32_vector_peak"] = (rl["alg_TFLOPs_kernel"] / FP32_VECTOR_PEAK_TFLOPS) if rl["alg_TFLOPs_kernel"] else None
+    # north_star's HBM model as a fraction, stated so that no reader has to derive it: it EXCEEDS 1 because the four waves
+    # of a block share the particle rows through L1 and the blocks of an XCD through L2 -- the model is not a bound
+    if kms > 0:
+        rl["alg_bytes_frac"] = (ncomp * b_alg / 1e9) / (kms / 1e3) / HBM_PEAK_GBS
+        rl["alg_bytes_note"] = ("algorithmic bytes (8 N (N/2+1) per comparison, SURVEY.md 8d) / launch time / 8 TB/s; "
+                                "above 1 by cache reuse (L1 69 %, L2 90 % hit rate), counter traffic is hbm.frac_of_peak")
     hbm = {"peak_GBps": HBM_PEAK_GBS, "alg_bytes_per_comparison": b_alg,
            "alg_GBps": (ncomp * b_alg / 1e9) / (kms / 1e3) if kms > 0 else None,
            "alg_note": "north-star model (one particle half-spectrum per comparison); L1/L2 reuse makes it exceed the "
@@ -381,7 +468,8 @@ def main():
                 pmc["config"]["particles"] == W.nP and pmc["config"]["ctf"] == W.nCTF and
                 pmc["config"]["displacements"] == int(W.pd.NtotDisp))
         from bioem_amd.buildinfo import source_blobs
-        stale = [k for k, v in source_blobs().items() if pmc.get("source_blobs", {}).get(k) != v]
+        # (the sources of the measured kernel's own translation unit: bioem_amd/buildinfo.py)
+        stale = [k for k, v in source_blobs(sig).items() if pmc.get("source_blobs", {}).get(k) != v]
         if same and stale:
             same = False
             rl["counters_refused"] = ("profiles/pmc_current.json was measured on other device sources (git blob hash "
@@ -410,6 +498,20 @@ def main():
     out["roofline"] = rl
     out["hbm"] = hbm
 
+    if world == 1:
+        # the TIMED pass checks itself: its last step's block must be finite, must select the planted orientation
+        # (particle p was rendered from orientation (7919 p) mod orientations) for most particles, and one more
+        # (untimed) step on the same inputs must reproduce it bit for bit
+        a = last[0] if K else last
+        rerun = one_step()
+        b = rerun[0] if K else rerun
+        planted = (7919 * np.arange(nMaps)) % W.nOrient
+        rec = float((a["orient"] == planted).mean())
+        fin = bool(np.isfinite(a["Constoadd"]).all() and (a["Total"] > 0).all() and np.isfinite(a["Total"]).all())
+        bit = bool(a.tobytes() == b.tobytes())
+        out["result_check"] = {"of": "the last timed step", "finite": fin, "planted_orientation_recovered": rec,
+                               "bitwise_equal_to_untimed_rerun": bit, "ok": bool(fin and bit and rec >= 0.9)}
+    out["particle_stack"] = stack_source
     if world > 1 and rank == 0:
         # the merged block, checked: arg-max orientations are global indices, and the planted truth (particle p was
         # rendered from orientation (7919 p) mod orientations of block 0) is what most particles must select
@@ -452,6 +554,12 @@ def main():
     if rank == 0:
         print(json.dumps(out))
     if world > 1:
+        dist.barrier()
+        if stack_file and rank == 0:
+            try:
+                os.unlink(stack_file)
+            except OSError:
+                pass
         dist.destroy_process_group()
 
 

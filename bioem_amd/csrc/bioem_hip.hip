@@ -38,43 +38,28 @@
 //   fold_kernels.hpp     k_fold_wave, k_fold_angles (k_fold: serial variant): fold the per-comparison partials into the probability block in the
 //                          reference's (orientation, CTF) order (bioem_algorithm.h:96-123, bioem.cpp:1527-1600)
 //   this file            device context, launch logic, the C ABI
+//   kernels_*.hip        one translation unit per comparison-kernel family (the instantiations of kernel_table.inc),
+//                          linked into the same library: kernels_fast, kernels_fastm, kernels_wide2_{short,16,long},
+//                          kernels_odd; this file keeps the generic kernel, the preparation, fold and merge kernels
 //
 // Numerics: float expressions that the reference evaluates in float are written in the same order and the
 // file is compiled with -ffp-contract=off (FMAs only where fmaf() is spelled out).  Sums that the reference
 // accumulates sequentially in float (sumsquareC, particle sums) are accumulated in the same order.
-#include <hip/hip_runtime.h>
+#define BIOEM_MAIN_TU 1 // the non-template kernels shared headers hold (k_posterior_consts) are compiled here only
+#include "engine_types.hpp"
+
 #include <rccl/rccl.h> // types only: the library itself is loaded on the first bioem_hip_merge (dlopen)
 
 #include <dlfcn.h>
 
-#include <algorithm>
-#include <cmath>
-#include <cstdio>
-#include <cstdlib>
-#include <cstring>
 #include <map>
 #include <mutex>
 #include <queue>
 #include <string>
 #include <vector>
 
-#include "bioem_hip.h"
-
-#define MIN_PROB (-999999.)
-
 namespace
 {
-
-struct Partial
-{
-  double sumExp;
-  float best;
-  int id;
-  float value;
-  int pad;
-};
-
-typedef bioem_hip_param_device PD;
 
 // ------------------------------------------------------------------------------------------------
 // error handling

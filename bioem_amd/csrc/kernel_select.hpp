@@ -35,54 +35,55 @@ namespace
 typedef void (*fast_kernel_t)(const CompareArgs);
 
 // ------------------------------------------------------------------------------------------------
-// registry
+// registry: the family tables live in their own translation units (kernels_*.hip, engine_types.hpp); an experiment
+// build (BIOEM_SLIM, scripts/slim_build.sh) is this one file with the instantiations named on the command line
 // ------------------------------------------------------------------------------------------------
-enum KernelFamily
-{
-  KF_GENERIC = 0,
-  KF_FAST,   // k_compare_fast<WD, R, NYQ, GS>            windows of at most 21 rows
-  KF_FASTM,  // k_compare_fastm<WD, R, NYQ, GS>           27- / 31-row windows, window pass on the matrix cores
-  KF_WIDE2,  // k_compare_wide2<R, NRW, NBLK, NYQ, HALVES, NW>  wide windows, row FFT
-  KF_ROWS,   // k_compare_rows<WD, GS>                    odd N, direct column sums
-  KF_ODDFFT  // k_compare_oddfft<WD, R>                   odd N with a factor 3 / 5 / 9 / 15 / 25
-};
+typedef BioemKernelEntry KernelEntry;
 
-struct KernelEntry
-{
-  int family;
-  int a[6];
-  fast_kernel_t fn;
-};
-
-#define K_FAST(WD, R, NYQ, GS) {KF_FAST, {WD, R, NYQ, GS, 0, 0}, k_compare_fast<WD, R, NYQ, GS>},
-#define K_FASTM(WD, R, NYQ, GS) {KF_FASTM, {WD, R, NYQ, GS, 0, 0}, k_compare_fastm<WD, R, NYQ, GS>},
-#define K_WIDE2(R, NRW, NBLK, NYQ, HALVES, NW)                                                                     \
-  {KF_WIDE2, {R, NRW, NBLK, NYQ, HALVES, NW}, k_compare_wide2<R, NRW, NBLK, NYQ, HALVES, NW>},
-#define K_ROWS(WD, GS) {KF_ROWS, {WD, GS, 0, 0, 0, 0}, k_compare_rows<WD, GS>},
-#define K_ODDFFT(WD, R) {KF_ODDFFT, {WD, R, 0, 0, 0, 0}, k_compare_oddfft<WD, R>},
-
-const KernelEntry kKernelTable[] = {
 #ifdef BIOEM_SLIM
-// experiment builds (scripts/slim_build.sh, never shipped): only the instantiations named on the command line
+const KernelEntry kSlimTable[] = {
 #ifdef BIOEM_SLIM_FAST
-    {KF_FAST, {BIOEM_SLIM_FAST, 0, 0}, k_compare_fast<BIOEM_SLIM_FAST>},
+    {KF_FAST, {BIOEM_SLIM_FAST, 0, 0}, reinterpret_cast<const void *>(k_compare_fast<BIOEM_SLIM_FAST>)},
 #endif
 #ifdef BIOEM_SLIM_FASTM
-    {KF_FASTM, {BIOEM_SLIM_FASTM, 0, 0}, k_compare_fastm<BIOEM_SLIM_FASTM>},
+    {KF_FASTM, {BIOEM_SLIM_FASTM, 0, 0}, reinterpret_cast<const void *>(k_compare_fastm<BIOEM_SLIM_FASTM>)},
 #endif
 #ifdef BIOEM_SLIM_W2
-    {KF_WIDE2, {BIOEM_SLIM_W2}, k_compare_wide2<BIOEM_SLIM_W2>},
+    {KF_WIDE2, {BIOEM_SLIM_W2}, reinterpret_cast<const void *>(k_compare_wide2<BIOEM_SLIM_W2>)},
 #endif
-#else
-#include "kernel_table.inc"
+    {KF_GENERIC, {0, 0, 0, 0, 0, 0}, reinterpret_cast<const void *>(k_compare_generic)}};
 #endif
-    {KF_GENERIC, {0, 0, 0, 0, 0, 0}, k_compare_generic}};
 
 fast_kernel_t find_kernel(int family, int a0 = 0, int a1 = 0, int a2 = 0, int a3 = 0, int a4 = 0, int a5 = 0)
 {
-  for (const KernelEntry &e : kKernelTable)
-    if (e.family == family && e.a[0] == a0 && e.a[1] == a1 && e.a[2] == a2 && e.a[3] == a3 && e.a[4] == a4 && e.a[5] == a5)
-      return e.fn;
+  if (family == KF_GENERIC)
+    return k_compare_generic;
+  const KernelEntry *tabs[8];
+  int cnt[8], nt = 0;
+#ifdef BIOEM_SLIM
+  tabs[nt] = kSlimTable;
+  cnt[nt++] = (int) (sizeof(kSlimTable) / sizeof(kSlimTable[0]));
+#else
+  switch (family)
+  {
+  case KF_FAST: tabs[nt] = bioem_kernels_fast(&cnt[nt]); nt++; break;
+  case KF_FASTM: tabs[nt] = bioem_kernels_fastm(&cnt[nt]); nt++; break;
+  case KF_WIDE2:
+    tabs[nt] = bioem_kernels_wide2_short(&cnt[nt]); nt++;
+    tabs[nt] = bioem_kernels_wide2_16(&cnt[nt]); nt++;
+    tabs[nt] = bioem_kernels_wide2_long(&cnt[nt]); nt++;
+    break;
+  default: tabs[nt] = bioem_kernels_odd(&cnt[nt]); nt++; break;
+  }
+#endif
+  for (int t = 0; t < nt; t++)
+    for (int i = 0; i < cnt[t]; i++)
+    {
+      const KernelEntry &e = tabs[t][i];
+      if (e.fn && e.family == family && e.a[0] == a0 && e.a[1] == a1 && e.a[2] == a2 && e.a[3] == a3 && e.a[4] == a4 &&
+          e.a[5] == a5)
+        return reinterpret_cast<fast_kernel_t>(const_cast<void *>(e.fn));
+    }
   return nullptr;
 }
 

@@ -38,6 +38,7 @@ __device__ __forceinline__ void logpro_consts(const PD &pd, const bioem_hip_para
 }
 
 // the two constants of every (orientation, CTF) row of a launch, for the comparison kernels to read
+#ifdef BIOEM_MAIN_TU
 __global__ __launch_bounds__(64) void k_posterior_consts(const bioem_hip_param5 *__restrict__ params, const PD pd,
                                                          double2 *__restrict__ out, int n)
 {
@@ -49,6 +50,7 @@ __global__ __launch_bounds__(64) void k_posterior_consts(const bioem_hip_param5 
     out[i] = make_double2(t2, prior);
   }
 }
+#endif
 
 __device__ __forceinline__ double logpro_eval(const PD &pd, const bioem_hip_param5 &q, float cc, float sumref,
                                               float sumsqref, double t2, double prior)

@@ -19,13 +19,39 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LLVM = "/opt/rocm/lib/llvm/bin"
 
 
-def extract_code_object(so, workdir):
+class ToolMissing(Exception):
+    pass
+
+
+def tool(name):
+    path = os.path.join(LLVM, name)
+    if not os.path.exists(path):
+        raise ToolMissing(path)
+    return path
+
+
+def extract_code_objects(so, workdir):
+    """The library is linked from one object per kernel family: .hip_fatbin holds one offload bundle per translation
+    unit (magic __CLANG_OFFLOAD_BUNDLE__), each with its own gfx950 code object."""
     fat = os.path.join(workdir, "fatbin")
-    co = os.path.join(workdir, "gfx950.co")
-    subprocess.check_call([os.path.join(LLVM, "llvm-objcopy"), "--dump-section", ".hip_fatbin=" + fat, so])
-    subprocess.check_call([os.path.join(LLVM, "clang-offload-bundler"), "--unbundle", "--type=o", "--input=" + fat,
-                           "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", "--output=" + co])
-    return co
+    subprocess.check_call([tool("llvm-objcopy"), "--dump-section", ".hip_fatbin=" + fat, so])
+    blob = open(fat, "rb").read()
+    magic = b"__CLANG_OFFLOAD_BUNDLE__"
+    starts = []
+    at = blob.find(magic)
+    while at >= 0:
+        starts.append(at)
+        at = blob.find(magic, at + 1)
+    cos = []
+    for k, st in enumerate(starts):
+        part = os.path.join(workdir, "bundle%d" % k)
+        with open(part, "wb") as f:
+            f.write(blob[st:starts[k + 1] if k + 1 < len(starts) else len(blob)])
+        co = os.path.join(workdir, "gfx950_%d.co" % k)
+        subprocess.check_call([tool("clang-offload-bundler"), "--unbundle", "--type=o", "--input=" + part,
+                               "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", "--output=" + co])
+        cos.append(co)
+    return cos
 
 
 def demangle(names):
@@ -40,7 +66,7 @@ def short(name):
 
 
 def kernels_of(co):
-    notes = subprocess.check_output([os.path.join(LLVM, "llvm-readelf"), "--notes", co], text=True)
+    notes = subprocess.check_output([tool("llvm-readelf"), "--notes", co], text=True)
     # the per-kernel maps list their keys alphabetically; a kernel's block ends at `.wavefront_size`
     ks, cur = [], {}
     for ln in notes.split("\n"):
@@ -64,7 +90,7 @@ def kernels_of(co):
 def waterfall_kernels(co):
     """Kernels in which a memory instruction sits in a waterfall loop (its buffer descriptor or address ended up in
     vector registers: 4 v_readfirstlane + 2 v_cmp + exec juggling around every load)."""
-    dis = subprocess.check_output([os.path.join(LLVM, "llvm-objdump"), "-d", "--no-show-raw-insn", co], text=True)
+    dis = subprocess.check_output([tool("llvm-objdump"), "-d", "--no-show-raw-insn", co], text=True)
     out, name, body = [], None, []
 
     def flush():
@@ -97,11 +123,24 @@ def main():
     ap.add_argument("--allow", default=None, help="regex of kernel names that may use scratch (diagnostic builds)")
     ap.add_argument("--quiet", action="store_true")
     a = ap.parse_args()
-    with tempfile.TemporaryDirectory() as d:
-        co = extract_code_object(a.so, d)
-        ks = kernels_of(co)
-        wf = waterfall_kernels(co)
-    names = demangle([k.get("name", k.get("symbol", "?")) for k in ks])
+    # a missing tool (or a tool that no longer understands the file) is not a spilling kernel: say so and leave with a
+    # code of its own (3), which `make check` / __graft_entry__.build() report without failing the product build
+    try:
+        if subprocess.run(["c++filt", "--version"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL).returncode:
+            raise ToolMissing("c++filt")
+        with tempfile.TemporaryDirectory() as d:
+            ks, wf = [], []
+            for co in extract_code_objects(a.so, d):
+                ks += kernels_of(co)
+                wf += waterfall_kernels(co)
+        names = demangle([k.get("name", k.get("symbol", "?")) for k in ks])
+    except (ToolMissing, FileNotFoundError, subprocess.CalledProcessError) as e:
+        print("check_code_object: code-object tools unavailable or failed (%s): check SKIPPED" % e, file=sys.stderr)
+        sys.exit(3)
+    if not ks:
+        print("check_code_object: no kernels found in %s (format of the code-object notes changed?): check SKIPPED" % a.so,
+              file=sys.stderr)
+        sys.exit(3)
     rows = []
     for k, n in zip(ks, names):
         alloc = -(-max(1, k.get("vgpr_count", 0) + k.get("agpr_count", 0)) // 8) * 8

@@ -151,7 +151,7 @@ def main():
     # identity of the device sources these counters belong to (bench.py refuses them on any other tree)
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     from bioem_amd.buildinfo import source_blobs
-    out["source_blobs"] = source_blobs()
+    out["source_blobs"] = source_blobs(out["kernel"])   # the kernel's own translation unit (kernels_*.hip + headers)
     out["notes"] = ("per-launch means over the launches of the dominant comparison kernel; durations for the rates are the "
                     "un-perturbed kernel-trace pass (kernel_stats.avg_ms); VGPR_Count field of rocprofv3 is in allocation "
                     "granules as reported, see the code object for the exact register count")

@@ -80,3 +80,33 @@ def test_config_selection_follows_baseline_json():
         assert (a.particles, a.defocus) == (64, 1)
     finally:
         sys.argv = argv
+
+
+def test_time_budget_trims_warmup_first_then_steps():
+    """--max-seconds: plan_steps is the pure function every rank evaluates with the same max-reduced numbers."""
+    import bench
+    # everything fits: nothing is trimmed
+    assert bench.plan_steps(20, 4, 1.0, 30.0, 480.0, 10.0) == (4, 20)
+    # config 3 on eight GPUs: 8.6 s per step, 60 s of set-up gone, 480 s budget, 10 s tail -> 47 steps fit: untouched
+    assert bench.plan_steps(20, 4, 8.6, 60.0, 480.0, 10.0) == (4, 20)
+    # a slower start: 200 s gone -> 31 fit -> 20 + 4 still fit
+    assert bench.plan_steps(20, 4, 8.6, 200.0, 480.0, 10.0) == (4, 20)
+    # 120 s budget: (120 - 40 - 10) / 8.6 = 8 steps fit: no further warm-up, eight timed steps
+    assert bench.plan_steps(20, 4, 8.6, 40.0, 120.0, 10.0) == (0, 8)
+    # warm-up is what goes first: 22 fit -> 2 of the 4 remaining warm-up steps, all 20 timed ones
+    assert bench.plan_steps(20, 4, 1.0, 448.0, 480.0, 10.0) == (2, 20)
+    # nothing fits any more: one timed step always runs (the line must exist), no warm-up
+    assert bench.plan_steps(20, 4, 8.6, 500.0, 480.0, 10.0) == (0, 1)
+    # no budget / no estimate: untouched
+    assert bench.plan_steps(20, 4, 8.6, 500.0, 0.0, 10.0) == (4, 20)
+    assert bench.plan_steps(20, 4, 0.0, 10.0, 480.0, 10.0) == (4, 20)
+
+
+def test_shared_stack_path_is_per_launch_and_per_shape(monkeypatch):
+    import bench
+    monkeypatch.setenv("MASTER_PORT", "29511")
+    a = bench.shared_stack_path((224, 10000, 4608, 5, 2))
+    b = bench.shared_stack_path((224, 1000, 4608, 5, 1))
+    assert a != b and a.startswith("/dev/shm/") and "29511" in a
+    monkeypatch.setenv("MASTER_PORT", "29512")
+    assert bench.shared_stack_path((224, 10000, 4608, 5, 2)) != a

@@ -576,8 +576,8 @@ def test_cli_accepts_the_reference_performance_knobs(tmp_path):
 REF_HIP = os.path.join(ROOT, "oracle", "_ref", "bioEM_ref_hip")
 
 
-@pytest.mark.skipif(not os.path.exists(REF_HIP), reason="oracle/_ref/bioEM_ref_hip is not on this box (it travels only "
-                    "with scripts/gpurun_with_reference.sh)")
+@pytest.mark.skipif(not os.path.exists(REF_HIP), reason="oracle/_ref/bioEM_ref_hip is not on this box (`make -C oracle "
+                    "ref_hip` builds it where /root/reference exists; it travels as test infrastructure)")
 @pytest.mark.parametrize("name", ["g10_n64", "g4_n32_angles", "g2_n128", "g7_n224", "g22_n128_wide40"])
 def test_reference_binary_drives_this_build(name, tmp_path):
     """The compiled drop-in against THIS build of libbioem_hip.so (the committed plugin outputs record one past run):
