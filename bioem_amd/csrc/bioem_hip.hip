@@ -110,7 +110,9 @@ struct bioem_hip_ctx
   // waves of a comparison, row FFT
   bool wide2 = false;
   bool fastm = false; // 23..31-row windows: k_compare_fastm (window pass on the matrix cores)
+  bool fastm2 = false; // 33..47-row windows: k_compare_fastm2 (rows split over the half-waves, 3 x 3 matrix tiles)
   int w2NRW = 0, w2NBLK = 0, w2TS = 0, w2Rows2 = 0, nyqWD = 0, w2Halves = 1, w2NW = 4;
+  float *dBtab = nullptr;  // k_compare_fastm2: tabulated B operand of the matrix pass
   float2 *dTwk2 = nullptr; // [N1][nd] recombination twiddles exp(2 pi i dx k1 / N), rows in sorted order
   float2 *dConvShift = nullptr;
   Partial *dPartTiles = nullptr;
@@ -217,6 +219,7 @@ struct bioem_hip_ctx
 #include "compare_fast.hpp"
 #include "compare_wide2.hpp"
 #include "compare_fastm.hpp"
+#include "compare_fastm2.hpp"
 #include "compare_generic.hpp"
 #include "compare_rows.hpp"
 #include "compare_direct.hpp"
@@ -299,6 +302,7 @@ int launch_compare_fold(bioem_hip_ctx *h, const BatchBuf &bb, int nOC, int orien
   a.disp = h->dDisp;
   a.ltab = h->dLtab;
   a.twk = h->dTwk;
+  a.btab = h->dBtab;
   a.tnyq = h->dTnyq;
   a.twnyq = h->dTwNyq;
   a.partials = h->dPartials;
@@ -364,6 +368,21 @@ int launch_compare_fold(bioem_hip_ctx *h, const BatchBuf &bb, int nOC, int orien
         hipLaunchKernelGGL(k_nyquist_rows<42>, gridq, dim3(256), 0, h->stream, aw);
     }
     hipLaunchKernelGGL(reinterpret_cast<fast_kernel_t>(const_cast<void *>(h->fn)), dim3((unsigned) ((size_t) nOC * h->nMaps)), dim3(64 * h->w2NW), h->ldsBytes, h->stream, aw);
+  }
+  else if (h->fastm2)
+  {
+    CompareArgs aw = a;
+    aw.twk = h->dTwk2;
+    aw.nyqWD = h->nyqWD;
+    if (h->nyq)
+    {
+      const dim3 gridq((unsigned) (((size_t) (h->nMaps + 15) / 16) * ((nOC + 15) / 16)));
+      if (h->nyqWD == 20)
+        hipLaunchKernelGGL(k_nyquist_rows<20>, gridq, dim3(256), 0, h->stream, aw);
+      else
+        hipLaunchKernelGGL(k_nyquist_rows<31>, gridq, dim3(256), 0, h->stream, aw);
+    }
+    hipLaunchKernelGGL(reinterpret_cast<fast_kernel_t>(const_cast<void *>(h->fn)), grid, dim3(256), h->ldsBytes, h->stream, aw);
   }
   else if (h->fast || h->rowsK)
   {
@@ -809,6 +828,7 @@ static int create_impl(bioem_hip_handle *out, int device, const bioem_hip_param_
     h->oddR = P.oddR;
     h->nyq = P.nyq;
     h->fastm = P.fastm;
+    h->fastm2 = P.fastm2;
     h->rowsK = P.rowsK;
     h->wide2 = P.wide2;
     h->tileT = P.tileT;
@@ -975,6 +995,44 @@ static int create_impl(bioem_hip_handle *out, int device, const bioem_hip_param_
     HIP_CHECK(h, hipMalloc(&h->dTwk2, sizeof(float2) * t2.size()));
     HIP_CHECK(h, hipMemcpy(h->dTwk2, t2.data(), sizeof(float2) * t2.size(), hipMemcpyHostToDevice));
   }
+  if (h->fastm2)
+  { // recombination twiddles of k_compare_fastm2: [k1 pair s][accumulator a = 8 g + j] = {w^(dx 2s), w^(dx (2s+1))} for the
+    // LOW-half row dx = 16 g + j - 23 (the high half folds the rows 8 further with the same numbers); zero for rows
+    // outside the window and for a k1 beyond N1 - 1
+    const int nS = (h->N1 + 1) / 2;
+    std::vector<float4> t4((size_t) nS * kFm2Acc, make_float4(0.f, 0.f, 0.f, 0.f));
+    for (int s2 = 0; s2 < nS; s2++)
+      for (int ac = 0; ac < kFm2Acc; ac++)
+      {
+        const long long dx = 16 * (ac / 8) + (ac % 8) - kFm2WD;
+        float w[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int e = 0; e < 2; e++)
+        {
+          const int k1 = 2 * s2 + e;
+          if (k1 >= h->N1)
+            continue;
+          const double ang = 2.0 * M_PI * (double) (((dx * k1) % N + N) % N) / (double) N;
+          w[2 * e] = (float) cos(ang);
+          w[2 * e + 1] = (float) sin(ang);
+        }
+        t4[(size_t) s2 * kFm2Acc + ac] = make_float4(w[0], w[1], w[2], w[3]);
+      }
+    HIP_CHECK(h, hipMalloc(&h->dTwk2, sizeof(float4) * t4.size()));
+    HIP_CHECK(h, hipMemcpy(h->dTwk2, t4.data(), sizeof(float4) * t4.size(), hipMemcpyHostToDevice));
+    // B operand of the matrix pass: lane l of k-step K, column tile ct supplies (l / 16 odd ? sin : cos)(2 pi ky dy / N),
+    // ky = 2 K + l / 32, dy = 16 ct + l % 16 - 23 -- the float twiddles exp(2 pi i k / N) every kernel uses
+    std::vector<float> bt(fastm2_btab_floats(h->H, h->nyq));
+    for (size_t K = 0; K < bt.size() / 192; K++)
+      for (int ct = 0; ct < 3; ct++)
+        for (int l = 0; l < 64; l++)
+        {
+          const long long ky = 2 * (long long) K + (l >> 5), dy = 16 * ct + (l & 15) - kFm2WD;
+          const double ang = 2.0 * M_PI * (double) (((ky * dy) % N + N) % N) / (double) N;
+          bt[(K * 3 + ct) * 64 + l] = ((l >> 4) & 1) ? (float) sin(ang) : (float) cos(ang);
+        }
+    HIP_CHECK(h, hipMalloc(&h->dBtab, sizeof(float) * bt.size()));
+    HIP_CHECK(h, hipMemcpy(h->dBtab, bt.data(), sizeof(float) * bt.size(), hipMemcpyHostToDevice));
+  }
   std::vector<float2> tw(N + 1);
   std::vector<double2> twd(N);
   for (int k = 0; k <= N; k++)
@@ -1035,7 +1093,7 @@ static int create_impl(bioem_hip_handle *out, int device, const bioem_hip_param_
     {
       fprintf(f, "%s\n", bioem_hip_kernel_signature(h));
       if (h->nyq)
-        fprintf(f, "k_nyquist_rows<%d>\n", h->wide2 ? h->nyqWD : h->winD);
+        fprintf(f, "k_nyquist_rows<%d>\n", (h->wide2 || h->fastm2) ? h->nyqWD : h->winD);
       fclose(f);
     }
   return 0;
@@ -1068,7 +1126,7 @@ int bioem_hip_destroy(bioem_hip_handle h)
                   h->dScratch, h->dConv,    h->dParams,   h->dPartials, h->dProb,
                   h->dProjReal2, h->dTempDen2, h->dRowSpec2, h->dSpecRef2, h->dScratch2, h->dConv2, h->dParams2,
                   h->dTnyq, h->dTwNyq, h->dPartTiles, h->dConvShift, h->dDispLocal, h->dRankOfRow, h->dTileCenter, h->dTileValid,
-                  h->dCand, h->dSend, h->dRecv, h->dMerged, h->dTwk2, h->dPostC, h->dPostC2,
+                  h->dCand, h->dSend, h->dRecv, h->dMerged, h->dTwk2, h->dBtab, h->dPostC, h->dPostC2,
                   h->dMapsReal, h->dConvReal, h->dDirectZ};
   for (void *p : ptrs)
     if (p)
@@ -1808,6 +1866,8 @@ const char *bioem_hip_kernel_name(bioem_hip_handle h)
     return "k_compare_direct";
   if (h->wide2)
     return "k_compare_wide2";
+  if (h->fastm2)
+    return "k_compare_fastm2";
   if (h->fastm)
     return "k_compare_fastm";
   if (h->fast)
@@ -1830,6 +1890,8 @@ const char *bioem_hip_kernel_signature(bioem_hip_handle h)
     else
       snprintf(buf, sizeof(buf), h->w2NW == 8 ? "k_compare_wide2<%d, %d, %d, %s, 1, 8>" : "k_compare_wide2<%d, %d, %d, %s>",
                2 * h->fast, h->w2NRW, h->w2NBLK, nq);
+  else if (h->fastm2)
+    snprintf(buf, sizeof(buf), "k_compare_fastm2<%d, %s>", 2 * h->fast, nq);
   else if (h->fastm)
     snprintf(buf, sizeof(buf), "k_compare_fastm<%d, %d, %s, %d>", h->winD, 2 * h->fast, nq, h->gs);
   else if (h->fast)

@@ -18,6 +18,7 @@ struct CompareArgs
   const double2 *ltab; // 64 x {c, -log c}
   const float2 *twk;   // [N1][2*WD+1] recombination twiddles exp(2 pi i d k1 / N), d = -WD..WD
   const float2 *twnyq; // [N/2][2*WD+1][2] twiddles of k_nyquist_rows (wave-uniform reads: wide scalar loads)
+  const float *btab;   // k_compare_fastm2: B operand of the matrix pass, [column pass][16][3][64] (fastm2_btab_floats)
   float *tnyq;         // [nMaps][ldPart][2*WD+1] Nyquist-column rows (fast path with the Nyquist split only)
   Partial *partials; // [nMaps][ldPart]
   int ldPart;

@@ -30,6 +30,7 @@ struct BioemKernelEntry
 #define BIOEM_HIDDEN __attribute__((visibility("hidden")))
 BIOEM_HIDDEN const BioemKernelEntry *bioem_kernels_fast(int *n);
 BIOEM_HIDDEN const BioemKernelEntry *bioem_kernels_fastm(int *n);
+BIOEM_HIDDEN const BioemKernelEntry *bioem_kernels_fastm2(int *n);
 BIOEM_HIDDEN const BioemKernelEntry *bioem_kernels_wide2_short(int *n); // register FFTs of 8..12 points
 BIOEM_HIDDEN const BioemKernelEntry *bioem_kernels_wide2_16(int *n);
 BIOEM_HIDDEN const BioemKernelEntry *bioem_kernels_wide2_long(int *n);  // 20..32 points
@@ -42,7 +43,8 @@ enum KernelFamily
   KF_FASTM,  // k_compare_fastm<WD, R, NYQ, GS>           27- / 31-row windows, window pass on the matrix cores
   KF_WIDE2,  // k_compare_wide2<R, NRW, NBLK, NYQ, HALVES, NW>  wide windows, row FFT
   KF_ROWS,   // k_compare_rows<WD, GS>                    odd N, direct column sums
-  KF_ODDFFT  // k_compare_oddfft<WD, R>                   odd N with a factor 3 / 5 / 9 / 15 / 25
+  KF_ODDFFT, // k_compare_oddfft<WD, R>                   odd N with a factor 3 / 5 / 9 / 15 / 25
+  KF_FASTM2  // k_compare_fastm2<R, NYQ>                  33..47-row windows: rows split over the half-waves, 3 x 3 MFMA tiles
 };
 
 namespace

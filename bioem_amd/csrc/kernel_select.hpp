@@ -48,6 +48,9 @@ const KernelEntry kSlimTable[] = {
 #ifdef BIOEM_SLIM_FASTM
     {KF_FASTM, {BIOEM_SLIM_FASTM, 0, 0}, reinterpret_cast<const void *>(k_compare_fastm<BIOEM_SLIM_FASTM>)},
 #endif
+#ifdef BIOEM_SLIM_FASTM2
+    {KF_FASTM2, {BIOEM_SLIM_FASTM2, 0, 0, 0, 0}, reinterpret_cast<const void *>(k_compare_fastm2<BIOEM_SLIM_FASTM2>)},
+#endif
 #ifdef BIOEM_SLIM_W2
     {KF_WIDE2, {BIOEM_SLIM_W2}, reinterpret_cast<const void *>(k_compare_wide2<BIOEM_SLIM_W2>)},
 #endif
@@ -68,6 +71,7 @@ fast_kernel_t find_kernel(int family, int a0 = 0, int a1 = 0, int a2 = 0, int a3
   {
   case KF_FAST: tabs[nt] = bioem_kernels_fast(&cnt[nt]); nt++; break;
   case KF_FASTM: tabs[nt] = bioem_kernels_fastm(&cnt[nt]); nt++; break;
+  case KF_FASTM2: tabs[nt] = bioem_kernels_fastm2(&cnt[nt]); nt++; break;
   case KF_WIDE2:
     tabs[nt] = bioem_kernels_wide2_short(&cnt[nt]); nt++;
     tabs[nt] = bioem_kernels_wide2_16(&cnt[nt]); nt++;
@@ -105,6 +109,12 @@ size_t fastm_lds_bytes(int N)
   // resting place of the 16 tile accumulators
   return (size_t) 2 * fastm_table_floats(N) * 4 + 128 + 1024 + (size_t) 4 * 2 * 32 * 33 * 4 + (size_t) 4 * 16 * 64 * 4;
 }
+size_t fastm2_lds_bytes(int N)
+{ // cos / sin planes of the twiddle table (padded), window ranks, log table, per wave the two 48 x 17 float planes /
+  // the resting place of the 36 tile accumulators
+  // (+ 256 B: the operand read of plane row 47, which holds no window row, may run past the last wave's planes)
+  return (size_t) 2 * fastm_table_floats(N) * 4 + 256 + 1024 + (size_t) 4 * kFm2WaveFloats * 4 + 256;
+}
 size_t wide2_lds_bytes(int N, int R, int rows2, int ts, int nw = 4)
 { // tables (twiddles, visiting ranks, log table, wave results, posterior constants) + max(one FFT-output slot per wave, T block)
   const size_t slots = (size_t) nw * R * 64 * 8, tblock = (size_t) rows2 * ts * 8;
@@ -121,7 +131,7 @@ struct KernelPlan
   int nd = 0, gs = 1, winD = 0;
   int family = KF_GENERIC;
   int fast = 0, N1 = 0, oddR = 0; // fast = register-FFT length / 2 (0: no register FFT)
-  bool nyq = false, fastm = false, rowsK = false, wide2 = false;
+  bool nyq = false, fastm = false, fastm2 = false, rowsK = false, wide2 = false;
   int tileT = 0, tilesPerAxis = 1;
   std::vector<int> tileCenter, tileValid;
   int w2NRW = 0, w2NBLK = 0, w2TS = 0, w2Rows2 = 0, nyqWD = 0, w2Halves = 1, w2NW = 4;
@@ -445,13 +455,35 @@ KernelPlan plan_kernels(int N, int maxD, int grid, int algo)
   // 1. one window kernel
   if (fitsWindow && plan_window_kernel(P, N, H, winD, true))
     return P;
+  // 2a. 33..47 rows at unit stride, N a multiple of 16: k_compare_fastm2 (one wave per comparison, rows split over the
+  //     half-waves; round 4: 224^2 +-20 px against k_compare_wide2<16, 11, 2>)
+  if (N % 16 == 0 && N >= 64 && symmetric && P.gs == 1 && P.nd >= 33 && P.nd <= 2 * kFm2WD + 1 && !getenv("BIOEM_NO_FASTM2"))
+  {
+    const bool nyq = BIOEM_NYQUIST_SPLIT && (N / 2) % 64 == 0;
+    if (const fast_kernel_t fn = find_kernel(KF_FASTM2, 16, nyq))
+    {
+      P.family = KF_FASTM2;
+      P.fastm2 = true;
+      P.fn = fn;
+      P.fast = 8;
+      P.N1 = N / 16;
+      P.nyq = nyq;
+      P.nyqWD = mD <= 20 ? 20 : 31;
+      if (nyq)
+        P.winD = P.nyqWD; // sizes the Nyquist pre-kernel's tables
+      P.ldsBytes = fastm2_lds_bytes(N);
+      return P;
+    }
+  }
   // 2. wide symmetric windows on even sizes: k_compare_wide2
   if (N % 2 == 0 && N >= 8 && symmetric && (P.nd > 31 || (getenv("BIOEM_FORCE_WIDE2") && P.nd >= 21)) &&
       !getenv("BIOEM_NO_WIDE2") && plan_wide2(P, N, H, mD))
     return P;
   // 3. tiles of a window kernel on phase-shifted conv spectra (window_tiles.hpp): launches^2 x the measured cost of one
   //    launch of the 21- / 27- / 31-row kernel (ms at 224^2: k_compare_fast 6.05, k_compare_fastm 6.5 / 6.7)
-  if (N >= 8 && symmetric && !fitsWindow && !getenv("BIOEM_NO_TILES"))
+  //    (also a window that fits one kernel whose instantiation is not in the table -- 31 rows at stride 4: it must not
+  //    drop to the generic kernel)
+  if (N >= 8 && symmetric && P.nd > 11 && !getenv("BIOEM_NO_TILES"))
   {
     static const int tileRows[3] = {21, 27, 31};
     static const double tileCost[3] = {6.05, 6.5, 6.7};
@@ -507,6 +539,7 @@ void plan_signature(const KernelPlan &P, char *buf, size_t cap)
                2 * P.fast, P.w2NRW, P.w2NBLK, nq);
     break;
   case KF_FASTM: snprintf(buf, cap, "k_compare_fastm<%d, %d, %s, %d>", P.winD, 2 * P.fast, nq, P.gs); break;
+  case KF_FASTM2: snprintf(buf, cap, "k_compare_fastm2<%d, %s>", 2 * P.fast, nq); break;
   case KF_FAST: snprintf(buf, cap, "k_compare_fast<%d, %d, %s, %d>", P.winD, 2 * P.fast, nq, P.gs); break;
   case KF_ODDFFT: snprintf(buf, cap, "k_compare_oddfft<%d, %d>", P.winD, P.oddR); break;
   case KF_ROWS: snprintf(buf, cap, "k_compare_rows<%d, %d>", P.winD, P.gs); break;

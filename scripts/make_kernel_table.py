@@ -26,6 +26,8 @@ def entry(sig):
         return "K_FAST(%s)" % ", ".join(args)
     if fam == "fastm":
         return "K_FASTM(%s)" % ", ".join(args)
+    if fam == "fastm2":
+        return "K_FASTM2(%s)" % ", ".join(args)
     if fam == "wide2":
         args += ["1", "4"][len(args) - 4:] if len(args) < 6 else []
         return "K_WIDE2(%s)" % ", ".join(args)

@@ -17,7 +17,7 @@ SIZES = [8, 10, 16, 24, 32, 34, 36, 40, 42, 44, 48, 50, 56, 60, 64, 72, 80, 84, 
          176, 180, 192, 200, 208, 210, 224, 240, 248, 250, 256, 264, 272, 280, 288, 290, 300, 320, 360, 380, 384, 400, 432,
          448, 512, 600, 9, 33, 35, 51, 75, 99, 125, 127, 129, 135, 225]
 WINDOWS = [0, 2, 4, 5, 7, 9, 10, 11, 12, 13, 14, 15, 16, 18, 20, 21, 22, 24, 25, 26, 27, 30, 33, 35, 37, 38, 40, 41, 42, 43,
-           44, 45, 47, 62, 64, 78, 80, 88]
+           44, 45, 47, 56, 60, 62, 64, 78, 80, 88]
 GRIDS = [1, 2, 3, 4, 5]
 
 

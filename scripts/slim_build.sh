@@ -8,4 +8,4 @@ name=$1; shift
 mkdir -p abl
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fno-slp-vectorize -fPIC -shared -std=c++17 \
   -Wno-unused-value -DBIOEM_SLIM "$@" -Iinclude -o abl/$name.so bioem_amd/csrc/bioem_hip.hip
-python scripts/check_code_object.py --so abl/$name.so 2>&1 | grep -E "k_compare_(fast|wide2)|kernels,"
+python scripts/check_code_object.py --so abl/$name.so 2>&1 | grep -E "k_compare_(fast|fastm2|wide2)|kernels,"

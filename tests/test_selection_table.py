@@ -1,6 +1,6 @@
 """Kernel selection (bioem_amd/csrc/kernel_select.hpp) without a GPU: bioem_hip_plan is a pure function of the image size
-and the displacement set.  The committed snapshot (tests/golden/selection_snapshot.txt.gz: 16 288 shapes -- 65 image
-sizes x 38 window half widths x grid spacings 1..5 x ALGO 1/2, written by scripts/selection_snapshot.py --plan) pins
+and the displacement set.  The committed snapshot (tests/golden/selection_snapshot.txt.gz: 16 856 shapes -- 65 image
+sizes x 40 window half widths x grid spacings 1..5 x ALGO 1/2, written by scripts/selection_snapshot.py --plan) pins
 what every shape runs; a change of the table or the rules shows up here as a diff, on purpose."""
 import ctypes as C
 import gzip
@@ -40,7 +40,7 @@ def test_every_table_entry_is_selected_by_some_shape_of_the_snapshot():
     for ln in open(os.path.join(ROOT, "bioem_amd", "csrc", "kernel_table.inc")):
         m = re.match(r"K_(\w+)\((.*)\)", ln.strip())
         if m:
-            fam = {"FAST": "fast", "FASTM": "fastm", "WIDE2": "wide2", "ROWS": "rows", "ODDFFT": "oddfft"}[m.group(1)]
+            fam = {"FAST": "fast", "FASTM": "fastm", "FASTM2": "fastm2", "WIDE2": "wide2", "ROWS": "rows", "ODDFFT": "oddfft"}[m.group(1)]
             table.add("k_compare_%s<%s>" % (fam, ",".join(a.strip() for a in m.group(2).split(","))))
     seen = set()
     with gzip.open(os.path.join(ROOT, "tests", "golden", "selection_snapshot.txt.gz"), "rt") as f:
@@ -62,6 +62,28 @@ def test_headline_shapes():
     assert plan(L, 128, 10, 1, 1) == "k_compare_fast<10, 32, true, 1>"             # config 1 / 4 (Nyquist split)
     assert plan(L, 256, 10, 1, 1) == "k_compare_fast<10, 32, true, 1>"             # config 5
     assert plan(L, 224, 13, 1, 1) == "k_compare_fastm<13, 16, false, 1>"           # 27 rows: matrix-core window pass
+    assert plan(L, 224, 20, 1, 1) == "k_compare_fastm2<16, false>"                 # 41 rows: rows split over the half-waves
+    assert plan(L, 128, 16, 1, 2) == "k_compare_fastm2<16, true>"
     assert plan(L, 224, 40, 1, 1) == "k_compare_wide2<32, 21, 2, false>"           # tutorial production window
     assert plan(L, 225, 10, 1, 1) == "k_compare_oddfft<10, 25>"
     assert plan(L, 224, 120, 1, 1) == "rejected"                                   # maxD >= N / 2
+
+
+def test_no_window_that_fits_a_kernel_falls_to_the_generic_one():
+    """A symmetric window of 13..31 rows on an even image size runs a window kernel or tiles of one, at every row stride
+    the table may lack (round 3 had no 31-row instantiation at stride 4: 114 <= N <= 519 with DISPLACE_CENTER 60 4 fell
+    to the direct pruned DFT)."""
+    import bioem_amd.engine as eng
+    L = eng.load_library()
+    bad = []
+    for N in list(range(64, 530, 6)) + [128, 224, 256]:
+        for g in (1, 2, 3, 4):
+            for m in (6, 10, 13, 14, 15):
+                d = m * g
+                if d >= N // 2:
+                    continue
+                for algo in (1, 2):
+                    sig = plan(L, N, d, g, algo)
+                    if "generic" in sig or sig == "rejected":
+                        bad.append((N, d, g, algo, sig))
+    assert not bad, bad[:8]
