@@ -177,6 +177,8 @@ struct bioem_hip_ctx
   float2 *dConv2 = nullptr;
   bioem_hip_param5 *dParams2 = nullptr;
   double2 *dPostC2 = nullptr;
+  // staged device entries (bioem_hip_project / _convolve / _compare_device): what each pipeline slot holds
+  int stageO0[2] = {0, 0}, stageNO[2] = {0, 0}, stageC0[2] = {0, 0}, stageNC[2] = {0, 0};
   hipEvent_t prepDone[2] = {nullptr, nullptr};
   hipEvent_t cmpDone[2] = {nullptr, nullptr};
   bool cmpPending[2] = {false, false};
@@ -1409,6 +1411,101 @@ int bioem_hip_project_convolve_compare_ctf(bioem_hip_handle h, int iOrientBegin,
     h->cmpPending[slot] = true;
   }
   // later main-stream work (finish_run, debug hooks) must also see prepStream drained: it is, through prepDone
+  return 0;
+}
+
+// ---- the three stages of the loop body as separate, asynchronous, batched entries (device-resident hand-over) ----
+int bioem_hip_project(bioem_hip_handle h, int iPipeline, int iOrientBegin, int iOrientEnd)
+{
+  HIP_CHECK(h, hipSetDevice(h->device));
+  const int slot = iPipeline & 1, nO = iOrientEnd - iOrientBegin;
+  if (!h->dPts || iOrientBegin < 0 || iOrientEnd > h->nAnglesUp || nO < 1)
+  {
+    h->err = "bioem_hip_project: model/orientations not uploaded or range invalid";
+    return 2;
+  }
+  if (iOrientBegin < h->angO0 || iOrientEnd > h->angO1)
+  {
+    h->err = "bioem_hip_project: orientations outside the range this shard handle was created for";
+    return 2;
+  }
+  if (nO > h->OB)
+  {
+    char buf[160];
+    snprintf(buf, sizeof(buf), "bioem_hip_project: at most %d orientations per call with this configuration", h->OB);
+    h->err = buf;
+    return 2;
+  }
+  if (compat_flush(h)) // rows staged through the reference-compatible entry go first (call order)
+    return 1;
+  // the comparison that last read this buffer set goes first (NOT the other set's: that one is what this call overlaps);
+  // with none queued, whatever the main stream holds so far (start_run, debug hooks, the compat entry)
+  if (!h->cmpPending[slot])
+    HIP_CHECK(h, hipEventRecord(h->cmpDone[slot], h->stream));
+  HIP_CHECK(h, hipStreamWaitEvent(h->prepStream, h->cmpDone[slot], 0));
+  h->cmpPending[slot] = false;
+  h->stageNO[slot] = h->stageNC[slot] = 0;
+  if (project_batch(h, batch_buf(h, slot), h->prepStream, iOrientBegin, nO))
+    return 1;
+  h->stageO0[slot] = iOrientBegin;
+  h->stageNO[slot] = nO;
+  return 0;
+}
+
+int bioem_hip_convolve(bioem_hip_handle h, int iPipeline, int iConvBegin, int iConvEnd)
+{
+  HIP_CHECK(h, hipSetDevice(h->device));
+  const int slot = iPipeline & 1, nC = iConvEnd - iConvBegin, nO = h->stageNO[slot];
+  if (nO < 1)
+  {
+    h->err = "bioem_hip_convolve: no projections in this pipeline slot (call bioem_hip_project first)";
+    return 2;
+  }
+  if (iConvBegin < 0 || iConvEnd > h->nCTF || nC < 1 || (long long) nO * nC > h->maxOC)
+  {
+    char buf[200];
+    snprintf(buf, sizeof(buf), "bioem_hip_convolve: CTF range invalid or more than %d (orientation, CTF) rows per call", h->maxOC);
+    h->err = buf;
+    return 2;
+  }
+  if (h->cmpPending[slot])
+  { // a comparison of this slot's previous conv rows is still queued: it reads what this call overwrites
+    HIP_CHECK(h, hipStreamWaitEvent(h->prepStream, h->cmpDone[slot], 0));
+    h->cmpPending[slot] = false;
+  }
+  if (convolve_batch(h, batch_buf(h, slot), h->prepStream, nO, iConvBegin, nC))
+    return 1;
+  HIP_CHECK(h, hipEventRecord(h->prepDone[slot], h->prepStream));
+  h->stageC0[slot] = iConvBegin;
+  h->stageNC[slot] = nC;
+  return 0;
+}
+
+int bioem_hip_compare_device(bioem_hip_handle h, int iPipeline)
+{
+  HIP_CHECK(h, hipSetDevice(h->device));
+  const int slot = iPipeline & 1, nO = h->stageNO[slot], nC = h->stageNC[slot];
+  if (nO < 1 || nC < 1)
+  {
+    h->err = "bioem_hip_compare_device: no conv spectra in this pipeline slot (call bioem_hip_project and bioem_hip_convolve first)";
+    return 2;
+  }
+  HIP_CHECK(h, hipStreamWaitEvent(h->stream, h->prepDone[slot], 0));
+  if (launch_compare_fold(h, batch_buf(h, slot), nO * nC, h->stageO0[slot], h->stageC0[slot], nC))
+    return 1;
+  HIP_CHECK(h, hipEventRecord(h->cmpDone[slot], h->stream));
+  h->cmpPending[slot] = true;
+  return 0;
+}
+
+int bioem_hip_max_batch(bioem_hip_handle h, int *maxOrientations, int *maxRows)
+{
+  if (!h)
+    return 2;
+  if (maxOrientations)
+    *maxOrientations = h->OB;
+  if (maxRows)
+    *maxRows = h->maxOC;
   return 0;
 }
 

@@ -15,6 +15,7 @@
 //   BIOEM_W2_R=<len>      register-FFT length of k_compare_wide2 where it divides N
 //   BIOEM_NO_TILES        no window tiles: what does not fit a kernel runs k_compare_generic
 //   BIOEM_TILE_ROWS=<t>   tile size of the tiled path (21, 27, 31)
+//   BIOEM_NO_FASTM2       33..47-row windows on k_compare_wide2 (k_compare_fastm2 off)
 //   BIOEM_NO_FASTM        27/31-row windows on tiles of the 21-row kernel (k_compare_fastm off)
 //   BIOEM_NO_ROWS_KERNEL  odd sizes on k_compare_generic
 //   BIOEM_NO_ODD_FFT      odd sizes on k_compare_rows (direct column sums) even where an odd register FFT divides N
@@ -457,7 +458,8 @@ KernelPlan plan_kernels(int N, int maxD, int grid, int algo)
     return P;
   // 2a. 33..47 rows at unit stride, N a multiple of 16: k_compare_fastm2 (one wave per comparison, rows split over the
   //     half-waves; round 4: 224^2 +-20 px against k_compare_wide2<16, 11, 2>)
-  if (N % 16 == 0 && N >= 64 && symmetric && P.gs == 1 && P.nd >= 33 && P.nd <= 2 * kFm2WD + 1 && !getenv("BIOEM_NO_FASTM2"))
+  if (N % 16 == 0 && N >= 64 && symmetric && P.gs == 1 && P.nd >= 33 && P.nd <= 2 * kFm2WD + 1 && !getenv("BIOEM_NO_FASTM2") &&
+      !getenv("BIOEM_FORCE_WIDE2"))
   {
     const bool nyq = BIOEM_NYQUIST_SPLIT && (N / 2) % 64 == 0;
     if (const fast_kernel_t fn = find_kernel(KF_FASTM2, 16, nyq))

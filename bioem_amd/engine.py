@@ -68,6 +68,10 @@ def load_library():
     L.bioem_hip_compare.argtypes = [vp, ci, ci, ci, ci, ci, vp, vp]
     L.bioem_hip_project_convolve_compare.argtypes = [vp, ci, ci]
     L.bioem_hip_project_convolve_compare_ctf.argtypes = [vp, ci, ci, ci, ci]
+    L.bioem_hip_project.argtypes = [vp, ci, ci, ci]
+    L.bioem_hip_convolve.argtypes = [vp, ci, ci, ci]
+    L.bioem_hip_compare_device.argtypes = [vp, ci]
+    L.bioem_hip_max_batch.argtypes = [vp, C.POINTER(ci), C.POINTER(ci)]
     L.bioem_hip_finish_run.argtypes = [vp, vp]
     L.bioem_hip_topk_angles.argtypes = [vp, ci, C.c_double, vp]
     L.bioem_hip_merge_topk_host.argtypes = [ci, ci, ci, C.POINTER(vp), vp]
@@ -100,7 +104,8 @@ EXPORTS = ["bioem_hip_device_count", "bioem_hip_create", "bioem_hip_create_shard
            "bioem_hip_debug_projection", "bioem_hip_debug_convolution", "bioem_hip_debug_particles",
            "bioem_hip_kernel_stats", "bioem_hip_reset_kernel_stats", "bioem_hip_uses_fast_path",
            "bioem_hip_kernel_name", "bioem_hip_kernel_signature", "bioem_hip_plan",
-           "bioem_hip_synchronize", "bioem_hip_r2c"]
+           "bioem_hip_synchronize", "bioem_hip_r2c", "bioem_hip_project", "bioem_hip_convolve",
+           "bioem_hip_compare_device", "bioem_hip_max_batch"]
 
 
 def _p(a):
@@ -225,6 +230,23 @@ class Engine:
 
     def project_convolve_compare_ctf(self, o0, o1, c0, c1):
         self._chk(self.L.bioem_hip_project_convolve_compare_ctf(self.h, o0, o1, c0, c1), "project_convolve_compare_ctf")
+
+    def project(self, iPipeline, o0, o1):
+        """== bioem::createProjection for [o0, o1), asynchronous; the spectra stay in buffer set iPipeline & 1"""
+        self._chk(self.L.bioem_hip_project(self.h, iPipeline, o0, o1), "project")
+
+    def convolve(self, iPipeline, c0, c1):
+        """== bioem::createConvolutedProjectionMap for the projections of the set x CTFs [c0, c1), asynchronous"""
+        self._chk(self.L.bioem_hip_convolve(self.h, iPipeline, c0, c1), "convolve")
+
+    def compare_device(self, iPipeline):
+        """== bioem::compareRefMaps for the conv spectra of the set, asynchronous"""
+        self._chk(self.L.bioem_hip_compare_device(self.h, iPipeline), "compare_device")
+
+    def max_batch(self):
+        a, b = C.c_int(), C.c_int()
+        self._chk(self.L.bioem_hip_max_batch(self.h, C.byref(a), C.byref(b)), "max_batch")
+        return a.value, b.value
 
     def finish_run(self, raw):
         assert raw.nbytes == self.prob_bytes()

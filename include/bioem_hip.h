@@ -152,6 +152,23 @@ int bioem_hip_project_convolve_compare(bioem_hip_handle h, int iOrientBegin, int
 int bioem_hip_project_convolve_compare_ctf(bioem_hip_handle h, int iOrientBegin, int iOrientEnd, int iConvBegin,
                                            int iConvEnd);
 
+/* The same three stages as separate entries, for an integrator who keeps the reference's loop (bioem.cpp:763-891) and
+ * replaces its body piece by piece: every call is asynchronous and batched, and what one stage produces stays on the
+ * device, in the comparison's layout, for the next.  iPipeline & 1 names one of two buffer sets, as in
+ * bioem::compareRefMaps (bioem.cpp:1388): stage calls on one set are ordered, the two sets overlap (projection and
+ * convolution of set 1 run beside the comparison of set 0).  Results are bit-identical to
+ * bioem_hip_project_convolve_compare over the same (orientation, CTF) rows in the same order.
+ *   bioem_hip_project         == bioem::createProjection (bioem.h:61, bioem.cpp:1604-1853) for [iOrientBegin, iOrientEnd),
+ *                                at most maxOrientations of bioem_hip_max_batch per call
+ *   bioem_hip_convolve        == bioem::createConvolutedProjectionMap (bioem.h:43-45, bioem.cpp:1855-1923) for every
+ *                                projection of the set x CTFs [iConvBegin, iConvEnd); rows (orientation-major) <= maxRows
+ *   bioem_hip_compare_device  == bioem::compareRefMaps (bioem.h:52-54) for the conv spectra of the set against all particles */
+int bioem_hip_project(bioem_hip_handle h, int iPipeline, int iOrientBegin, int iOrientEnd);
+int bioem_hip_convolve(bioem_hip_handle h, int iPipeline, int iConvBegin, int iConvEnd);
+int bioem_hip_compare_device(bioem_hip_handle h, int iPipeline);
+/* capacity of a buffer set: orientations per bioem_hip_project call, (orientation, CTF) rows per bioem_hip_convolve call */
+int bioem_hip_max_batch(bioem_hip_handle h, int *maxOrientations, int *maxRows);
+
 /* bioem_cuda::deviceFinishRun (bioem_cuda.cu:1013-1021): synchronise, download the probability block. */
 int bioem_hip_finish_run(bioem_hip_handle h, void *pProb_host);
 

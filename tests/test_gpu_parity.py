@@ -122,6 +122,52 @@ def test_reference_compatible_compare_entry(name):
     E.close()
 
 
+@pytest.mark.parametrize("name,split_ctf", [("g10_n64", False), ("g4_n32_angles", True), ("g2_n128", False),
+                                            ("g13_n32_psf_writectf", True)])
+def test_staged_device_entries_equal_the_fused_entry(name, split_ctf):
+    """bioem_hip_project / _convolve / _compare_device (createProjection, createConvolutedProjectionMap and compareRefMaps
+    as separate asynchronous batched entries, everything device-resident) against bioem_hip_project_convolve_compare
+    over the same (orientation, CTF) rows in the same order: bit-identical probability blocks (also the angle table), and
+    the oracle agrees.  Batches of three orientations alternate between the two buffer sets; with split_ctf every batch
+    is convolved and compared in two CTF ranges."""
+    import bioem_amd.engine as eng
+    case, S = setup_for(name)
+    algo = case["algos"][0]
+    E = make_engine(S, algo)
+    batches = [(o, min(o + 3, S.nAngles)) for o in range(0, S.nAngles, 3)]
+    cut = max(1, S.nCTF // 2)
+    ranges = [(0, cut), (cut, S.nCTF)] if (split_ctf and S.nCTF > 1) else [(0, S.nCTF)]
+    raw_f, pmap_f, _ = eng.new_prob_block(S.nMaps, S.nAngles, S.pd.writeAngles)
+    E.start_run(raw_f)
+    for o0, o1 in batches:
+        for c0, c1 in ranges:
+            E.project_convolve_compare_ctf(o0, o1, c0, c1)
+    E.finish_run(raw_f)
+    raw_s, pmap_s, _ = eng.new_prob_block(S.nMaps, S.nAngles, S.pd.writeAngles)
+    E.start_run(raw_s)
+    for b, (o0, o1) in enumerate(batches):
+        E.project(b, o0, o1)
+        for c0, c1 in ranges:
+            E.convolve(b, c0, c1)
+            E.compare_device(b)
+    E.finish_run(raw_s)
+    assert raw_s.tobytes() == raw_f.tobytes()
+    want, _ = S.run(algo)
+    assert_same_posterior(S, pmap_s, want)
+    maxO, maxRows = E.max_batch()
+    assert maxO >= 1 and maxRows >= S.nCTF
+    # error behaviour: stages out of order or beyond the capacity of a buffer set are refused with a message
+    E2 = make_engine(S, algo)
+    with pytest.raises(RuntimeError, match="bioem_hip_project first"):
+        E2.convolve(0, 0, S.nCTF)
+    with pytest.raises(RuntimeError, match="bioem_hip_project and bioem_hip_convolve first"):
+        E2.compare_device(1)
+    with pytest.raises(RuntimeError, match="range invalid"):
+        E2.project(0, 0, S.nAngles + 1)
+    E2.close()
+    E.close()
+
+
 @pytest.mark.parametrize("name,ring,order", [("g4_n32_angles", 4, "orient"), ("g4_n32_angles", 3, "ctf"),
                                              ("g10_n64", 5, "orient"), ("g8_n32_grid", 1, "orient"),
                                              ("g11_n32_eulerlist", 7, "ctf")])
