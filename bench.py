@@ -52,6 +52,9 @@ def parse_args():
     ap.add_argument("--defocus", type=int, default=None, help="CTF_DEFOCUS grid points (config 3: 2 x 5 envelopes = 10 CTFs)")
     ap.add_argument("--max-displacement", type=int, default=10, help="DISPLACE_CENTER half width (pixels)")
     ap.add_argument("--grid", type=int, default=1, help="DISPLACE_CENTER grid spacing")
+    ap.add_argument("--algo", type=int, choices=(1, 2), default=1,
+                    help="BIOEM_ALGO: 1 = doRefMapFFT (bioem_algorithm.h:144-198, the reference's default), 2 = "
+                         "doRefMap_CPU_Parallel / _Reduce (bioem.cpp:1461-1602); engine and CPU oracle alike")
     ap.add_argument("--write-angles", type=int, nargs="?", const=10, default=0, metavar="K",
                     help="WRITE_PROB_ANGLES K: keep the per-orientation table (on the device, sharded) and select the K "
                          "best orientations per particle")
@@ -188,7 +191,7 @@ def cpu_model():
     return "unknown"
 
 
-def cpu_baseline(W, n_orient, n_threads, repeats):
+def cpu_baseline(W, n_orient, n_threads, repeats, algo=1):
     """CPU oracle port (oracle/bioem_oracle.c: full c2r FFT cross-correlation + calProb loop, OpenMP over
     particles like bioem.cpp:1392) on `n_orient` orientations x all CTFs x all particles of this workload;
     median of `repeats` runs."""
@@ -219,7 +222,7 @@ def cpu_baseline(W, n_orient, n_threads, repeats):
         pmap = np.zeros(nP, dtype=orc.PROB_MAP_DTYPE)
         L.orc_init_prob(nP, len(W.angles), 0, pmap.ctypes.data, None)
         t0 = time.time()
-        L.orc_run(C.byref(pd), 1, pts.ctypes.data, len(pts), W.NormDen, W.angles.ctypes.data, len(W.angles), 1, W.px, 0,
+        L.orc_run(C.byref(pd), algo, pts.ctypes.data, len(pts), W.NormDen, W.angles.ctypes.data, len(W.angles), 1, W.px, 0,
                   0, W.nCTF, W.refCTF.ctypes.data, W.ctfParam.ctypes.data, nP, refFFT.ctypes.data, sumRef.ctypes.data,
                   sumsqRef.ctypes.data, 0, n_orient, pmap.ctypes.data, None)
         times.append(time.time() - t0)
@@ -274,7 +277,8 @@ def main():
     # same particle stack (from block 0, same seeds), i.e. the N = 1 workload's stack
     K = int(args.write_angles)
     wl = dict(N=args.pixels, nP=args.particles, nOrient=args.orientations, device=gpu_index, nEnv=args.envelopes,
-              nDefocus=args.defocus, maxD=args.max_displacement, grid=args.grid, write_angles=K, blocks=world, block=rank)
+              nDefocus=args.defocus, maxD=args.max_displacement, grid=args.grid, write_angles=K, blocks=world, block=rank,
+              algo=args.algo)
     stack_file = None
     if world > 1 and os.access("/dev/shm", os.W_OK) and not os.environ.get("BIOEM_BENCH_RENDER_PER_RANK"):
         stack_file = shared_stack_path((args.pixels, args.particles, args.orientations, args.envelopes, args.defocus))
@@ -425,7 +429,7 @@ def main():
                                                       args.max_displacement, args.grid, int(W.pd.NtotDisp),
                                                       (", WRITE_PROB_ANGLES %d" % K) if K else ""),
                    "pixels": W.N, "particles": W.nP, "orientations_per_gpu": W.nOrient, "ctf": W.nCTF,
-                   "displacements": int(W.pd.NtotDisp), "orientation_list": "seeded uniform random quaternions",
+                   "displacements": int(W.pd.NtotDisp), "algo": args.algo, "orientation_list": "seeded uniform random quaternions",
                    "fast_path": bool(E.fast_path), "cross_correlation": "direct (real-space sliding window)" if args.direct else "transform", "parallelism": "orientation blocks x%d, one RCCL all-gather + "
                    "log-sum-exp fold" % world},
     }
@@ -527,7 +531,7 @@ def main():
         # where neither tells the share (all 256 host cores visible, quota unlimited) BIOEM_CPU_THREADS sets it
         nthreads = orc.usable_cpus(cap=int(os.environ.get("BIOEM_CPU_THREADS", 1 << 20)))
         nco = min(args.cpu_orientations, W.nOrient)
-        v, times, want, const, particle_check = cpu_baseline(W, nco, nthreads, max(1, args.cpu_repeats))
+        v, times, want, const, particle_check = cpu_baseline(W, nco, nthreads, max(1, args.cpu_repeats), args.algo)
         import ctypes.util
         out["cpu_baseline"] = {"value": v, "unit": "comparisons/s", "cores": nthreads, "kind": "port",
                                "cpu_model": cpu_model(), "host_cores_total": os.cpu_count(),

@@ -205,6 +205,16 @@ struct bioem_hip_ctx
   hipStream_t copyStream = nullptr;
 
   // timing
+  // per-batch phase records (bioem_hip_set_phase_timing): the reference's BIOEM_DEBUG_OUTPUT report (timer.cpp:138-165,
+  // bioem.cpp:769-889) from HIP events on the streams the phases run on
+  struct PhaseEvents
+  {
+    int phase, o0, o1, c0, c1;
+    hipEvent_t a, b;
+  };
+  bool phaseTiming = false;
+  std::vector<PhaseEvents> phasePending;
+  std::vector<bioem_hip_phase_record> phaseDone;
   std::vector<hipEvent_t> evPool;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> evPending;
   double compareMs = 0;
@@ -264,6 +274,46 @@ void drain_events(bioem_hip_ctx *h)
     h->evPool.push_back(pr.second);
   }
   h->evPending.clear();
+}
+
+// phase timing: an event pair around a phase of a batch on the stream it runs on (no-ops unless enabled)
+int phase_begin(bioem_hip_ctx *h, hipStream_t st, int phase, int o0, int o1, int c0, int c1)
+{
+  if (!h->phaseTiming)
+    return 0;
+  bioem_hip_ctx::PhaseEvents e = {phase, o0, o1, c0, c1, get_event(h), get_event(h)};
+  if (!e.a || !e.b)
+  {
+    h->err = "hipEventCreate failed";
+    return 1;
+  }
+  HIP_CHECK(h, hipEventRecord(e.a, st));
+  h->phasePending.push_back(e);
+  return 0;
+}
+
+int phase_end(bioem_hip_ctx *h, hipStream_t st)
+{
+  if (!h->phaseTiming || h->phasePending.empty())
+    return 0;
+  HIP_CHECK(h, hipEventRecord(h->phasePending.back().b, st));
+  return 0;
+}
+
+void drain_phases(bioem_hip_ctx *h)
+{
+  for (auto &e : h->phasePending)
+  {
+    float ms = 0.f;
+    if (hipEventSynchronize(e.b) == hipSuccess && hipEventElapsedTime(&ms, e.a, e.b) == hipSuccess)
+    {
+      bioem_hip_phase_record r = {e.phase, e.o0, e.o1, e.c0, e.c1, (double) ms * 1e-3};
+      h->phaseDone.push_back(r);
+    }
+    h->evPool.push_back(e.a);
+    h->evPool.push_back(e.b);
+  }
+  h->phasePending.clear();
 }
 
 struct BatchBuf
@@ -340,6 +390,9 @@ int launch_compare_fold(bioem_hip_ctx *h, const BatchBuf &bb, int nOC, int orien
   // {t2, prior} of every row of the launch, once per row instead of once per comparison and lane
   hipLaunchKernelGGL(k_posterior_consts, dim3((nOC + 63) / 64), dim3(64), 0, h->stream, bb.params, h->pd, bb.postc, nOC);
   HIP_CHECK(h, hipEventRecord(e0, h->stream));
+  if (phase_begin(h, h->stream, BIOEM_HIP_PHASE_COMPARISON, ids ? -1 : orient0, ids ? -1 : orient0 + (nOC + convPerOrient - 1) / convPerOrient,
+                  ids ? -1 : conv0, ids ? -1 : conv0 + convPerOrient))
+    return 1;
   if (h->direct)
   {
     CompareArgs ad = a;
@@ -469,6 +522,8 @@ int launch_compare_fold(bioem_hip_ctx *h, const BatchBuf &bb, int nOC, int orien
                        pmap);
   }
   HIP_CHECK(h, hipGetLastError());
+  if (phase_end(h, h->stream)) // comparison = the kernels of the launch and the fold behind them (what compareRefMaps does)
+    return 1;
   if (h->evPending.size() > 512)
     drain_events(h);
   return 0;
@@ -1121,6 +1176,7 @@ int bioem_hip_destroy(bioem_hip_handle h)
   if (h->stream)
     hipStreamSynchronize(h->stream);
   drain_events(h);
+  drain_phases(h);
   for (hipEvent_t e : h->evPool)
     hipEventDestroy(e);
   void *ptrs[] = {h->dRef,     h->dSumRef,  h->dSumsqRef, h->dCTF,     h->dCtfParam, h->dPts,   h->dAngles,
@@ -1384,9 +1440,11 @@ int bioem_hip_project_convolve_compare_ctf(bioem_hip_handle h, int iOrientBegin,
       HIP_CHECK(h, hipStreamWaitEvent(h->prepStream, h->cmpDone[slot], 0));
       h->cmpPending[slot] = false;
     }
-    if (project_batch(h, bb, h->prepStream, o0, nO))
+    if (phase_begin(h, h->prepStream, BIOEM_HIP_PHASE_PROJECTION, o0, o0 + nO, 0, 0) || project_batch(h, bb, h->prepStream, o0, nO) ||
+        phase_end(h, h->prepStream))
       return 1;
-    if (convolve_batch(h, bb, h->prepStream, nO, iConvBegin, nC))
+    if (phase_begin(h, h->prepStream, BIOEM_HIP_PHASE_CONVOLUTION, o0, o0 + nO, iConvBegin, iConvBegin + nC) ||
+        convolve_batch(h, bb, h->prepStream, nO, iConvBegin, nC) || phase_end(h, h->prepStream))
       return 1;
     HIP_CHECK(h, hipEventRecord(h->prepDone[slot], h->prepStream));
     return 0;
@@ -1445,7 +1503,8 @@ int bioem_hip_project(bioem_hip_handle h, int iPipeline, int iOrientBegin, int i
   HIP_CHECK(h, hipStreamWaitEvent(h->prepStream, h->cmpDone[slot], 0));
   h->cmpPending[slot] = false;
   h->stageNO[slot] = h->stageNC[slot] = 0;
-  if (project_batch(h, batch_buf(h, slot), h->prepStream, iOrientBegin, nO))
+  if (phase_begin(h, h->prepStream, BIOEM_HIP_PHASE_PROJECTION, iOrientBegin, iOrientEnd, 0, 0) ||
+      project_batch(h, batch_buf(h, slot), h->prepStream, iOrientBegin, nO) || phase_end(h, h->prepStream))
     return 1;
   h->stageO0[slot] = iOrientBegin;
   h->stageNO[slot] = nO;
@@ -1473,7 +1532,8 @@ int bioem_hip_convolve(bioem_hip_handle h, int iPipeline, int iConvBegin, int iC
     HIP_CHECK(h, hipStreamWaitEvent(h->prepStream, h->cmpDone[slot], 0));
     h->cmpPending[slot] = false;
   }
-  if (convolve_batch(h, batch_buf(h, slot), h->prepStream, nO, iConvBegin, nC))
+  if (phase_begin(h, h->prepStream, BIOEM_HIP_PHASE_CONVOLUTION, h->stageO0[slot], h->stageO0[slot] + nO, iConvBegin, iConvEnd) ||
+      convolve_batch(h, batch_buf(h, slot), h->prepStream, nO, iConvBegin, nC) || phase_end(h, h->prepStream))
     return 1;
   HIP_CHECK(h, hipEventRecord(h->prepDone[slot], h->prepStream));
   h->stageC0[slot] = iConvBegin;
@@ -1517,6 +1577,30 @@ int bioem_hip_finish_run(bioem_hip_handle h, void *pProb_host)
   HIP_CHECK(h, hipMemcpyAsync(pProb_host, h->dProb, h->probBytes, hipMemcpyDeviceToHost, h->stream));
   HIP_CHECK(h, hipStreamSynchronize(h->stream));
   drain_events(h);
+  drain_phases(h);
+  return 0;
+}
+
+int bioem_hip_set_phase_timing(bioem_hip_handle h, int on)
+{
+  if (!h)
+    return 2;
+  h->phaseTiming = on != 0;
+  return 0;
+}
+
+int bioem_hip_phase_records(bioem_hip_handle h, bioem_hip_phase_record *out, int cap, int *n)
+{
+  if (!h || !n || cap < 0 || (cap > 0 && !out))
+    return 2;
+  HIP_CHECK(h, hipSetDevice(h->device));
+  drain_phases(h);
+  const int have = (int) h->phaseDone.size();
+  *n = have;
+  for (int i = 0; i < have && i < cap; i++)
+    out[i] = h->phaseDone[i];
+  if (cap >= have)
+    h->phaseDone.clear();
   return 0;
 }
 

@@ -12,6 +12,8 @@ PROB_MAP_DTYPE = np.dtype([("Total", "<f8"), ("Constoadd", "<f8"), ("cent_x", "<
 PROB_ANGLE_DTYPE = np.dtype([("forAngles", "<f8"), ("ConstAngle", "<f8")])
 PARAM5_DTYPE = np.dtype([("amp", "<f4"), ("pha", "<f4"), ("env", "<f4"), ("sumC", "<f4"), ("sumsquareC", "<f4")])
 POINT_DTYPE = np.dtype([("pos", "<f4", (3,)), ("quat4", "<f4"), ("radius", "<f4"), ("density", "<f4")])
+PHASE_RECORD_DTYPE = np.dtype([("phase", "<i4"), ("iOrientBegin", "<i4"), ("iOrientEnd", "<i4"), ("iConvBegin", "<i4"),
+                               ("iConvEnd", "<i4"), ("pad", "<i4"), ("seconds", "<f8")])
 CANDIDATE_DTYPE = np.dtype([("forAngles", "<f8"), ("ConstAngle", "<f8"), ("logp", "<f8"), ("orient", "<i4"),
                             ("pad", "<i4")])
 MIN_PROB = -999999.0
@@ -73,6 +75,8 @@ def load_library():
     L.bioem_hip_compare_device.argtypes = [vp, ci]
     L.bioem_hip_max_batch.argtypes = [vp, C.POINTER(ci), C.POINTER(ci)]
     L.bioem_hip_finish_run.argtypes = [vp, vp]
+    L.bioem_hip_set_phase_timing.argtypes = [vp, ci]
+    L.bioem_hip_phase_records.argtypes = [vp, vp, ci, C.POINTER(ci)]
     L.bioem_hip_topk_angles.argtypes = [vp, ci, C.c_double, vp]
     L.bioem_hip_merge_topk_host.argtypes = [ci, ci, ci, C.POINTER(vp), vp]
     L.bioem_hip_merge.argtypes = [C.POINTER(vp), ci, vp, ci, C.c_double, vp]
@@ -105,7 +109,7 @@ EXPORTS = ["bioem_hip_device_count", "bioem_hip_create", "bioem_hip_create_shard
            "bioem_hip_kernel_stats", "bioem_hip_reset_kernel_stats", "bioem_hip_uses_fast_path",
            "bioem_hip_kernel_name", "bioem_hip_kernel_signature", "bioem_hip_plan",
            "bioem_hip_synchronize", "bioem_hip_r2c", "bioem_hip_project", "bioem_hip_convolve",
-           "bioem_hip_compare_device", "bioem_hip_max_batch"]
+           "bioem_hip_compare_device", "bioem_hip_max_batch", "bioem_hip_set_phase_timing", "bioem_hip_phase_records"]
 
 
 def _p(a):
@@ -247,6 +251,18 @@ class Engine:
         a, b = C.c_int(), C.c_int()
         self._chk(self.L.bioem_hip_max_batch(self.h, C.byref(a), C.byref(b)), "max_batch")
         return a.value, b.value
+
+    def set_phase_timing(self, on):
+        self._chk(self.L.bioem_hip_set_phase_timing(self.h, int(bool(on))), "set_phase_timing")
+
+    def phase_records(self):
+        """per-batch device time of projection (0) / convolution (1) / comparison (2) since set_phase_timing(True)"""
+        n = C.c_int()
+        self._chk(self.L.bioem_hip_phase_records(self.h, None, 0, C.byref(n)), "phase_records")
+        out = np.zeros(n.value, dtype=PHASE_RECORD_DTYPE)
+        if n.value:
+            self._chk(self.L.bioem_hip_phase_records(self.h, _p(out), n.value, C.byref(n)), "phase_records")
+        return out
 
     def finish_run(self, raw):
         assert raw.nbytes == self.prob_bytes()

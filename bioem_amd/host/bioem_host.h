@@ -105,6 +105,7 @@ public:
   ~Driver();
   int configure(int argc, char **argv); // bioem.cpp:438-585
   int run();                            // bioem.cpp:659-1377
+  void print_phase_report();            // BIOEM_DEBUG_OUTPUT >= 1: timer.cpp:156-165, bioem.cpp:769-889
   void cleanup();
 
   InputParams param;

@@ -275,6 +275,69 @@ int Driver::configure(int ac, char **av)
   return 0;
 }
 
+// BIOEM_DEBUG_OUTPUT >= 1: the reference's per-phase report (bioem.cpp:769-889 "Time Projection / Convolution /
+// Comparison" lines, TimeStat::PrintTimeStat timer.cpp:156-165 SUMMARY lines) from the engine's HIP-event records -- device
+// time per batch of the pipeline; a shard stands where the reference prints its MPI rank
+void Driver::print_phase_report()
+{
+  static const char *names[4] = {"Total time of projection", "Projection", "Convolution", "Comparison"};
+  for (int g = 0; g < (int) shards.size(); g++)
+  {
+    int n = 0;
+    if (bioem_hip_phase_records(shards[g].h, nullptr, 0, &n) || n == 0)
+      continue;
+    std::vector<bioem_hip_phase_record> rec(n);
+    if (bioem_hip_phase_records(shards[g].h, rec.data(), n, &n))
+      continue;
+    std::vector<double> logs[4];
+    double batchTotal = 0.;
+    for (int i = 0; i < n; i++)
+    {
+      const bioem_hip_phase_record &r = rec[i];
+      if (r.phase == BIOEM_HIP_PHASE_PROJECTION)
+      {
+        if (debugOutput >= 2)
+          printf("\tTime Projection %d-%d: %f (rank %d)\n", r.iOrientBegin, r.iOrientEnd - 1, r.seconds, g);
+        logs[1].push_back(r.seconds);
+      }
+      else if (r.phase == BIOEM_HIP_PHASE_CONVOLUTION)
+      {
+        if (debugOutput >= 2)
+          printf("\t\tTime Convolution %d-%d %d-%d: %f (rank %d)\n", r.iOrientBegin, r.iOrientEnd - 1, r.iConvBegin,
+                 r.iConvEnd - 1, r.seconds, g);
+        logs[2].push_back(r.seconds);
+      }
+      else
+      {
+        if (debugOutput >= 2)
+          printf("\t\tTime Comparison %d-%d %d-%d: %f sec (rank %d)\n", r.iOrientBegin, r.iOrientEnd - 1, r.iConvBegin,
+                 r.iConvEnd - 1, r.seconds, g);
+        logs[3].push_back(r.seconds);
+      }
+      batchTotal += r.seconds;
+      // a batch ends with its (last) comparison: the reference's "Total time for projection" per orientation
+      if (r.phase == BIOEM_HIP_PHASE_COMPARISON && (i + 1 == n || rec[i + 1].phase != BIOEM_HIP_PHASE_COMPARISON))
+      {
+        logs[0].push_back(batchTotal);
+        batchTotal = 0.;
+      }
+    }
+    for (int k = 0; k < 4; k++)
+    {
+      if (logs[k].empty())
+        continue;
+      double sum = 0., sq = 0.;
+      for (double v : logs[k])
+        sum += v;
+      const double mean = sum / logs[k].size();
+      for (double v : logs[k])
+        sq += (v - mean) * (v - mean);
+      printf("SUMMARY -> %s: Total %f sec; Mean %f sec; Std.Dev. %f (rank %d)\n", names[k], sum, mean,
+             sqrt(sq / logs[k].size()), g);
+    }
+  }
+}
+
 int Driver::run()
 {
   printf("\tInitializing Probabilities\n");
@@ -319,7 +382,9 @@ int Driver::run()
     th.emplace_back([&, g]() {
       Shard &sh = shards[g];
       bioem_hip_handle h = sh.h;
-      int rc = bioem_hip_start_run(h, sh.prob);
+      int rc = bioem_hip_set_phase_timing(h, debugOutput >= 1);
+      if (!rc)
+        rc = bioem_hip_start_run(h, sh.prob);
       if (!rc && !splitCTF)
         rc = bioem_hip_project_convolve_compare(h, sh.o0, sh.o1);
       // CTF split: the shard's run of (orientation, CTF) pairs, one rectangle per orientation it touches
@@ -341,6 +406,8 @@ int Driver::run()
   for (int g = 0; g < nShards; g++)
     if (!errs[g].empty())
       fatal("shard %d: %s", g, errs[g].c_str());
+  if (debugOutput >= 1)
+    print_phase_report();
 
   // ---- the path's single exchange step: merge of the shards (bioem.cpp:909-1044) ----
   prob.assign(sizeof(bioem_hip_prob_map) * (size_t) nMaps, 0);

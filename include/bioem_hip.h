@@ -204,6 +204,25 @@ int bioem_hip_merge(bioem_hip_handle *handles, int n, void *pProbMaps_host, int 
  * `device`; replaces the fftwf_execute_dft_r2c call of the PSF kernel set-up (param.cpp:1521). */
 int bioem_hip_r2c(int device, int N, int nImg, const float *in, float *out);
 
+/* The reference's only built-in profile, BIOEM_DEBUG_OUTPUT >= 1 (TimeStat, timer.cpp:138-165; the "Time Projection /
+ * Convolution / Comparison" lines of bioem.cpp:769-889): device time of every phase of every batch, from HIP events on
+ * the streams the phases run on.  Off by default; records accumulate from set_phase_timing(h, 1) on and are handed over
+ * (and dropped) by phase_records after finish_run: *n = records available, the first min(*n, cap) are written. */
+enum
+{
+  BIOEM_HIP_PHASE_PROJECTION = 0, /* bioem::createProjection of orientations [iOrientBegin, iOrientEnd) */
+  BIOEM_HIP_PHASE_CONVOLUTION = 1, /* createConvolutedProjectionMap of those x CTFs [iConvBegin, iConvEnd) */
+  BIOEM_HIP_PHASE_COMPARISON = 2   /* compareRefMaps of those rows against all particles, fold included */
+};
+typedef struct
+{
+  int phase;
+  int iOrientBegin, iOrientEnd, iConvBegin, iConvEnd; /* -1: rows handed over through bioem_hip_compare */
+  double seconds;
+} bioem_hip_phase_record;
+int bioem_hip_set_phase_timing(bioem_hip_handle h, int on);
+int bioem_hip_phase_records(bioem_hip_handle h, bioem_hip_phase_record *out, int cap, int *n);
+
 /* ---- instrumentation / test hooks (no reference equivalent) ---- */
 /* projection spectrum of one orientation in reference layout [N][N/2+1][2] */
 int bioem_hip_debug_projection(bioem_hip_handle h, int iOrient, float *spec_out);

@@ -619,6 +619,77 @@ def test_cli_accepts_the_reference_performance_knobs(tmp_path):
         assert (g["angles"], g["ctf"], g["cx"], g["cy"]) == (m["angles"], m["ctf"], m["cx"], m["cy"])
 
 
+@pytest.mark.parametrize("name,nO", [("g2_n128", 24), ("g7_n224", 8)])
+@pytest.mark.parametrize("algo", [1, 2])
+def test_psf_mode_at_128_and_224_against_oracle(name, nO, algo, tmp_path):
+    """USE_PSF (param.cpp:1466-1535: real-space kernel on the wrapped radius, r2c; calc_logpro's PSF prior,
+    bioem_algorithm.h:59-66) at the BASELINE image sizes: the golden PSF cases are 32^2.  Model, particles and
+    orientations of a golden case with its CTF lines replaced by a PSF grid; device engine against the oracle."""
+    case, _ = setup_for(name)
+    txt = open(os.path.join(case["dir"], "param.txt")).read().split("\n")
+    txt = [ln for ln in txt if ln and not ln.startswith("CTF_")]
+    txt += ["USE_PSF", "PSF_AMPLITUDE 0.1 0.3 2", "PSF_ENVELOPE 0.02 0.08 2", "PSF_PHASE 0.01 0.05 1"]
+    pf = tmp_path / "param_psf.txt"
+    pf.write_text("\n".join(txt) + "\n")
+    P = orc.parse_param_file(str(pf))
+    assert P["usepsf"]
+    S = orc.Setup(P, case["model"], case["maps"], case["orient_lines"], debug_break=nO)
+    assert int(S.pd.tousepsf) == 1 and S.nCTF == 4
+    E = make_engine(S, algo)
+    _, pmap, _ = run_native(E, S)
+    want, _ = S.run(algo)
+    assert_same_posterior(S, pmap, want)
+    E.close()
+
+
+def test_cli_debug_output_prints_the_reference_phase_report(tmp_path):
+    """BIOEM_DEBUG_OUTPUT: the reference's built-in profile (timer.cpp:156-165, bioem.cpp:769-889) -- the four SUMMARY
+    lines at level 1, the per-batch "Time Projection / Convolution / Comparison" lines at level 2, in its formats; the
+    output file does not change."""
+    import re
+    exe = os.path.join(ROOT, "bioem_amd", "bin", "bioEM")
+    case, S = setup_for("g10_n64")
+    cmd = [exe, "--Inputfile", os.path.join(case["dir"], "param.txt"), "--OutputFile", "out.txt"] + \
+        write_case_inputs(case, tmp_path)
+    outs = {}
+    for level in ("0", "1", "2"):
+        r = subprocess.run(cmd, cwd=str(tmp_path), env=dict(os.environ, BIOEM_GPUS="1", BIOEM_DEBUG_OUTPUT=level),
+                           stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
+        assert r.returncode == 0, r.stdout[-2000:]
+        outs[level] = (r.stdout, open(tmp_path / "out.txt").read())
+    assert outs["0"][1] == outs["1"][1] == outs["2"][1]
+    assert "SUMMARY" not in outs["0"][0]
+    summary = re.compile(r"^SUMMARY -> (Total time of projection|Projection|Convolution|Comparison): Total \d+\.\d{6} sec; "
+                         r"Mean \d+\.\d{6} sec; Std\.Dev\. \d+\.\d{6} \(rank 0\)$", re.M)
+    for level in ("1", "2"):
+        names = [m.group(1) for m in summary.finditer(outs[level][0])]
+        assert names == ["Total time of projection", "Projection", "Convolution", "Comparison"], outs[level][0][-1500:]
+    assert "Time Projection" not in outs["1"][0]
+    two = outs["2"][0]
+    assert re.search(r"^\tTime Projection 0-\d+: \d+\.\d{6} \(rank 0\)$", two, re.M)
+    assert re.search(r"^\t\tTime Convolution 0-\d+ 0-\d+: \d+\.\d{6} \(rank 0\)$", two, re.M)
+    assert re.search(r"^\t\tTime Comparison 0-\d+ 0-\d+: \d+\.\d{6} sec \(rank 0\)$", two, re.M)
+
+
+def test_phase_records_cover_every_batch_of_a_pass():
+    import bioem_amd.engine as eng
+    case, S = setup_for("g10_n64")
+    E = make_engine(S, 1)
+    E.set_phase_timing(True)
+    raw, pmap, _ = eng.new_prob_block(S.nMaps, S.nAngles, 0)
+    E.start_run(raw)
+    E.project_convolve_compare(0, S.nAngles)
+    E.finish_run(raw)
+    rec = E.phase_records()
+    assert len(rec) >= 3 and set(rec["phase"]) == {0, 1, 2} and (rec["seconds"] > 0).all()
+    for ph in (0, 1, 2):                 # the batches of each phase tile [0, nAngles)
+        r = rec[rec["phase"] == ph]
+        assert r["iOrientBegin"][0] == 0 and r["iOrientEnd"][-1] == S.nAngles
+        assert (r["iOrientBegin"][1:] == r["iOrientEnd"][:-1]).all()
+    assert len(E.phase_records()) == 0   # handed over once
+    E.close()
+
+
 REF_HIP = os.path.join(ROOT, "oracle", "_ref", "bioEM_ref_hip")
 
 
@@ -771,6 +842,24 @@ def test_full_size_slice_against_oracle(full_workload):
     want, const = oracle_on_workload(W, sel, nO)
     _, got = run_workload(W, 0, nO)
     assert_workload_matches(got, want, const, sel)
+
+
+@pytest.mark.parametrize("N,nP,nEnv,nDef,maxD", [(224, 1000, 5, 1, 10),     # config 2's stack and CTF grid
+                                                 (224, 2000, 5, 2, 10),     # config 3's ten CTFs
+                                                 (256, 400, 2, 2, 10),      # config 5's image size (Nyquist split)
+                                                 (224, 200, 2, 1, 20)])     # 41-row window (k_compare_fastm2)
+def test_algo2_at_baseline_sizes_against_oracle(N, nP, nEnv, nDef, maxD):
+    """BIOEM_ALGO=2 (doRefMap_CPU_Parallel / _Reduce, bioem.cpp:1461-1602) at the BASELINE image sizes and particle
+    counts -- the full-size checks above run ALGO 1: 6 orientations x all CTFs x 8 particles through the oracle."""
+    from bioem_amd.synthetic import Workload
+    W = Workload(N=N, nP=nP, nOrient=32, nEnv=nEnv, nDefocus=nDef, maxD=maxD, algo=2)
+    try:
+        sel = [0, 1, 2, 3, nP // 2, nP // 2 + 1, nP - 2, nP - 1]
+        want, const = oracle_on_workload(W, sel, 6, algo=2)
+        _, got = run_workload(W, 0, 6)
+        assert_workload_matches(got, want, const, sel)
+    finally:
+        W.engine.close()
 
 
 # ------------------------------------------------------------------------------------------------------
