@@ -52,10 +52,13 @@ __device__ unsigned long long g_w2_stamps[16];
 // NW = 8: eight waves per comparison (512-thread blocks) -- half the window rows per wave, so that the 16-point
 // instantiation with 11 rows per wave (110 registers) covers windows of up to 88 rows at FOUR waves per SIMD with two
 // blocks per CU, and larger images / windows keep a register-sized share per wave
+#ifndef BIOEM_W2_HALVES_WAVES
+#define BIOEM_W2_HALVES_WAVES 2 // (experiment builds: 3 = the halves kernels under the three-wave register bound)
+#endif
 template <int R, int NRW, int NBLK, bool NYQ, int HALVES = 1, int NW = 4>
 // waves per SIMD the registers must allow: the T block in halves means its LDS footprint holds a CU to two blocks anyway
 __global__ __launch_bounds__(64 * NW, NW == 8 ? ((NRW * NBLK <= 26 && R <= 16) ? 4 : 2)
-                                      : HALVES == 2 ? 2
+                                      : HALVES == 2 ? BIOEM_W2_HALVES_WAVES
                                                     : ((NRW * NBLK <= 42 && R <= 16) ? 3 : 2)) void k_compare_wide2(const CompareArgs a)
 {
   constexpr int R2 = R / 2;
@@ -176,7 +179,10 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? ((NRW * NBLK <= 26 && R <= 16) ?
   // LDS position of window row d's residue row inside a slot: lane addresses held in registers over the column pass,
   // except in the 8-point instantiations, which form the wave-uniform part on the scalar side where it is used
   // (measured: registers +1 % for R >= 16, scalar +8 % for R = 8 at 120^2 +-25 px)
-  constexpr bool YOFF_REGS = R > 8 && !(HALVES == 2 && NBLK >= 3) && !(HALVES == 2 && NRW > 21);
+  #ifndef BIOEM_W2_YOFF
+#define BIOEM_W2_YOFF 1
+#endif
+  constexpr bool YOFF_REGS = BIOEM_W2_YOFF && R > 8 && !(HALVES == 2 && NBLK >= 3) && !(HALVES == 2 && NRW > 21);
   const int dx0 = (r0 - mD) * gs;
   const int res0 = ((dx0 % R) + R) % R; // residue of the wave's first row; row d: (res0 + d gs) mod R
   int yoff[YOFF_REGS ? NRW : 1];

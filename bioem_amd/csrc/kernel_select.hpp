@@ -200,6 +200,9 @@ const Wide2Rule kWide2Rules[] = {
     {"two blocks, eight waves", 2, 2, 8, 11, W2_LEN_EIGHT_WAVE, 43, 2, false},
     // the two-wave kernels: 224^2 +-40 px 7.2 (tiled) -> 14.5, 256^2 +-40 px 6.1 -> 11.1 (T block in halves), 320^2 +-40 px
     // 4.1 -> 6.8 (three blocks), 208^2 +-42 px 3.2 -> 10.3 (24 rows per wave), 512^2 +-20 px 3.3 -> 4.7 (four blocks)
+    // (round 4, measured and not kept: six waves per comparison with four rotating producer slots -- 163 registers, three
+    //  waves per SIMD on paper -- 224^2 +-40 px 8.7 against 15.3 M/s: a 6-wave block lands 2/1/2/1 on the four SIMDs and a
+    //  second block of the same shape does not fit beside it at three waves per SIMD, so one block per CU ran)
     {"one block, 32 rows per wave", 1, 1, 4, 32, W2_LEN_LONGEST, 43, 1, false},
     {"two blocks, 21 rows per wave", 2, 2, 4, 21, W2_LEN_LONGEST, 43, 2, true},
     {"two blocks, 24 rows per wave", 2, 2, 4, 24, W2_LEN_LONGEST, 43, 2, true},
