@@ -27,28 +27,51 @@ def n_gpus():
 
 
 def run_ranks(backend, name, outdir, world=2):
+    """Starts the ranks and watches ALL of them (as bench.self_launch does): a rank that dies -- say at handle creation --
+    would otherwise leave the survivor in the rendezvous or the all-gather until its own time-out before the failure is
+    reported.  Every rank's output goes to a file (a pipe nobody drains while polling could fill up)."""
+    import tempfile
+    import time
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
-    procs = []
+    procs, logs = [], []
     for r in range(world):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        logs.append(tempfile.NamedTemporaryFile(prefix="rccl_rank%d_" % r, suffix=".log", delete=False))
         procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "rccl_worker.py"), backend, name,
-                                       str(outdir)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
-    outs = []
+                                       str(outdir)], env=env, stdout=logs[-1], stderr=subprocess.STDOUT))
+    deadline = time.time() + 300
+    failed = None
+    while failed is None and time.time() < deadline:
+        codes = [p.poll() for p in procs]
+        bad = [r for r, c in enumerate(codes) if c not in (None, 0)]
+        if bad:
+            failed = bad[0]
+        elif all(c == 0 for c in codes):
+            break
+        else:
+            time.sleep(0.2)
+    for p in procs:
+        if p.poll() is None:
+            p.terminate()          # the exact children this test started, by handle
     for p in procs:
         try:
-            o, _ = p.communicate(timeout=300)
+            p.wait(timeout=5)
         except subprocess.TimeoutExpired:
-            for q in procs:
-                if q.poll() is None:
-                    q.kill()
-            raise
-        outs.append(o.decode(errors="replace"))
+            p.kill()
+            p.wait()
+    outs = []
+    for f in logs:
+        f.close()
+        with open(f.name, errors="replace") as g:
+            outs.append(g.read())
+        os.unlink(f.name)
+    assert failed is None, "rank %d failed (the other ranks were terminated):\n%s" % (failed, outs[failed][-3000:])
     for r, p in enumerate(procs):
-        assert p.returncode == 0, "rank %d:\n%s" % (r, outs[r][-3000:])
+        assert p.returncode == 0, "rank %d (timed out?):\n%s" % (r, outs[r][-3000:])
 
 
 def check_against_unsharded(name, outdir, world=2):
