@@ -1053,15 +1053,16 @@ static int create_impl(bioem_hip_handle *out, int device, const bioem_hip_param_
     HIP_CHECK(h, hipMemcpy(h->dTwk2, t2.data(), sizeof(float2) * t2.size(), hipMemcpyHostToDevice));
   }
   if (h->fastm2)
-  { // recombination twiddles of k_compare_fastm2: [k1 pair s][accumulator a = 8 g + j] = {w^(dx 2s), w^(dx (2s+1))} for the
-    // LOW-half row dx = 16 g + j - 23 (the high half folds the rows 8 further with the same numbers); zero for rows
-    // outside the window and for a k1 beyond N1 - 1
+  { // recombination twiddles of k_compare_fastm2<R>: [k1 pair s][accumulator a = (R / 2) g + j] = {w^(dx 2s), w^(dx (2s+1))} for
+    // the LOW-half row dx = R g + j - 23 (the high half folds the rows R / 2 further with the same numbers); zero for a k1
+    // beyond N1 - 1 (rows outside the displacement list are masked by their rank in the kernel)
+    const int Rl = 2 * h->fast, nAcc = fastm2_acc(Rl);
     const int nS = (h->N1 + 1) / 2;
-    std::vector<float4> t4((size_t) nS * kFm2Acc, make_float4(0.f, 0.f, 0.f, 0.f));
+    std::vector<float4> t4((size_t) nS * nAcc, make_float4(0.f, 0.f, 0.f, 0.f));
     for (int s2 = 0; s2 < nS; s2++)
-      for (int ac = 0; ac < kFm2Acc; ac++)
+      for (int ac = 0; ac < nAcc; ac++)
       {
-        const long long dx = 16 * (ac / 8) + (ac % 8) - kFm2WD;
+        const long long dx = Rl * (ac / (Rl / 2)) + (ac % (Rl / 2)) - kFm2WD;
         float w[4] = {0.f, 0.f, 0.f, 0.f};
         for (int e = 0; e < 2; e++)
         {
@@ -1072,7 +1073,7 @@ static int create_impl(bioem_hip_handle *out, int device, const bioem_hip_param_
           w[2 * e] = (float) cos(ang);
           w[2 * e + 1] = (float) sin(ang);
         }
-        t4[(size_t) s2 * kFm2Acc + ac] = make_float4(w[0], w[1], w[2], w[3]);
+        t4[(size_t) s2 * nAcc + ac] = make_float4(w[0], w[1], w[2], w[3]);
       }
     HIP_CHECK(h, hipMalloc(&h->dTwk2, sizeof(float4) * t4.size()));
     HIP_CHECK(h, hipMemcpy(h->dTwk2, t4.data(), sizeof(float4) * t4.size(), hipMemcpyHostToDevice));

@@ -17,7 +17,7 @@ namespace
 // This kernel halves the accumulators: a column pass covers 32 frequency columns, lane l and lane l + 32 work on the
 // SAME column.  In a step the low half forms spectrum product and register FFT of k1 = 2 s, the high half of
 // k1 = 2 s + 1 -- no lane idles --, then
-//     v_permlane32_swap (y[p], y[p + 8])       p = (j - WD) mod 16, j = 0..7        (gfx950; 16 per step)
+//     v_permlane32_swap (y[p], y[p + 8])       p = (j - WD) mod 16, j = 0..7        (gfx950; 16 per step; R = 16 shown)
 // leaves in register y[p] the k1 = 2 s outputs and in y[p + 8] the k1 = 2 s + 1 outputs -- residue p in the low half,
 // residue p + 8 in the high half.  The low half owns the window rows m = 16 g + j, the high half the rows
 // m = 16 g + 8 + j (g = 0..2, j = 0..7): rows 8 apart have residues 8 apart, so ONE register serves accumulator (g, j)
@@ -32,69 +32,54 @@ namespace
 // cost 64 accumulators and 1.8x the matrix-pipe time.
 // Rows m = 0..46 hold dx = m - 23 for EVERY window of the family (+-16 ... +-23 px): rows outside the displacement list
 // get zero twiddles and a rank of -1 -- the cost does not depend on the width inside the family (48 rows either way).
-// R = 16 only (N a multiple of 16); an odd N1 = N / 16 leaves the high half of the last step reading beyond the
-// buffer descriptor's range, which returns zeros: its contribution vanishes without a branch.
+// R = 16, or 12 / 10 / 8 where 16 does not divide N (rows 8 / 6 / 5 / 4 apart pair up; 3 / 4 / 5 / 6 groups of R rows,
+// 24 or 25 accumulators); an odd N1 = N / R leaves the high half of the last step reading beyond the buffer
+// descriptor's range, which returns zeros: its contribution vanishes without a branch.
 // ------------------------------------------------------------------------------------------------
 typedef float floatx4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2s __attribute__((ext_vector_type(2)));
 
-constexpr int kFm2WD = 23;   // window rows m = 0..2 WD hold dx = m - WD
-constexpr int kFm2Rows = 48; // three 16-row tiles
-constexpr int kFm2Acc = 24;  // complex accumulators per lane
-// T reaches the A-operand planes 16 or 32 columns at a time.  32 columns (one exchange per column pass, every lane
-// writes): two planes of 47 rows x 33 floats = 12.1 KiB per wave still leave three blocks per CU (row 47 holds no window
-// row: it is neither written nor, where it is read as an operand, used)
-#ifndef BIOEM_FM2_C32
-#define BIOEM_FM2_C32 1
-#endif
-// the B operand of the matrix pass (cos | sin of 2 pi ky dy / N in operand order) from a table in global memory instead
-// of the LDS twiddle table with per-step index arithmetic (30 vector instructions per k-step, and a 64-bit modulo per
-// exchange: 4.6 k of the 19.0 k vector instructions per comparison at 224^2)
-#ifndef BIOEM_FM2_BTAB
-#define BIOEM_FM2_BTAB 1
-#endif
+constexpr int kFm2WD = 23;        // window rows m = 0..2 WD hold dx = m - WD
+constexpr int kFm2Rows = 48;      // three 16-row tiles
+constexpr int kFm2PS = 33;        // plane row stride in floats (32 columns + 1: the 16 rows of a tile hit 16 banks)
+constexpr int kFm2PlaneRows = 47; // row 47 holds no window row: neither written nor, where it is read as an operand, used
+// LDS floats per wave: the two A-operand planes (12.1 KiB); between matrix passes the same space holds the 36 tile
+// accumulators of every lane
+constexpr int kFm2WaveFloats = 36 * 64 > 2 * kFm2PlaneRows * kFm2PS ? 36 * 64 : 2 * kFm2PlaneRows * kFm2PS;
+// groups of R rows and complex accumulators per lane for a register FFT of length R: rows m = R g + (R / 2) half + j
+__host__ __device__ constexpr int fastm2_groups(int R) { return (2 * kFm2WD + R) / R; }
+__host__ __device__ constexpr int fastm2_acc(int R) { return fastm2_groups(R) * (R / 2); }
+// the B operand of the matrix pass -- (lane / 16 odd ? sin : cos)(2 pi ky dy / N), ky = 2 K + lane / 32, dy = 16 ct + lane
+// % 16 - 23 -- is the same matrix for every comparison: tabulated on the host, [column pass][16 k-steps][3 column
+// tiles][64 lanes] floats (index arithmetic on the LDS twiddle table cost 30 vector instructions per k-step and a
+// 64-bit modulo per exchange: 19.0 k -> 17.0 k vector instructions per comparison at 224^2)
 __host__ __device__ constexpr int Hlim0(int H, bool nyq) { return nyq ? H - 1 : H; }
-// floats of the table: [column pass][16 k-steps][3 column tiles][64 lanes]
 __host__ __device__ constexpr size_t fastm2_btab_floats(int H, bool nyq) { return (size_t) ((Hlim0(H, nyq) + 31) / 32) * 16 * 3 * 64; }
-constexpr int kFm2PS = BIOEM_FM2_C32 ? 33 : 17; // plane row stride in floats (columns + 1: the 16 rows of a tile hit 16 banks)
-constexpr int kFm2PlaneRows = BIOEM_FM2_C32 ? 47 : 48;
-constexpr int kFm2WaveFloats = 36 * 64 > 2 * kFm2PlaneRows * kFm2PS ? 36 * 64 : 2 * kFm2PlaneRows * kFm2PS; // LDS floats per wave
 
-// recombination twiddles of the low rows, [k1 pair s][accumulator a] = {w^(dx 2s), w^(dx (2s+1))}, dx = 16 g + j - WD
+// recombination twiddles of the low rows, [k1 pair s][accumulator a = (R / 2) g + j] = {w^(dx 2s), w^(dx (2s+1))},
+// dx = R g + j - WD
 typedef const float4 __attribute__((address_space(4))) *const_float4_ptr;
 
-#ifndef BIOEM_FM2_WAVES
-#define BIOEM_FM2_WAVES 3
-#endif
 template <int R, bool NYQ>
-__global__ __launch_bounds__(256, BIOEM_FM2_WAVES) void k_compare_fastm2(const CompareArgs a)
+__global__ __launch_bounds__(256, 3) void k_compare_fastm2(const CompareArgs a)
 {
-  static_assert(R == 16, "16-point register FFT");
+  static_assert(R == 16 || R == 12 || R == 10 || R == 8, "register FFT of 16, 12, 10 or 8 points");
   constexpr int WD = kFm2WD, NWR = 2 * WD + 1;
-  constexpr int R2 = R / 2, RD = 4;
-  constexpr int PS = kFm2PS, PLANE = kFm2PlaneRows * PS; // 16 columns: 816 floats = 16 mod 32, the re and im planes sit 16 banks apart
-  constexpr int CX = BIOEM_FM2_C32 ? 32 : 16;         // columns per exchange
+  constexpr int R2 = R / 2;                 // row pairs of a step = rows between the halves' rows
+  constexpr int RD = (R2 % 4 == 0) ? 4 : (R2 % 3 == 0) ? 3 : R2; // operand ring depth (divides R2)
+  constexpr int NACC = fastm2_acc(R);       // 24 (25 for R = 10)
+  constexpr int P0 = ((-WD) % R + R) % R;   // residue of window row 0
+  constexpr int PS = kFm2PS, PLANE = kFm2PlaneRows * PS;
   extern __shared__ __align__(16) unsigned char smem[];
   const int N = a.N, H = a.H, N1 = a.N1;
-  const int NT = fastm_table_floats(N);
-  float *tcos = reinterpret_cast<float *>(smem);
-  int *rankW = reinterpret_cast<int *>(smem + (size_t) 2 * NT * 4);                // 48 ints (256 B reserved)
-  double2 *ltab = reinterpret_cast<double2 *>(smem + (size_t) 2 * NT * 4 + 256);     // 64 entries
-  float *Pall = reinterpret_cast<float *>(smem + (size_t) 2 * NT * 4 + 256 + 1024);
+  int *rankW = reinterpret_cast<int *>(smem);                // 48 ints (256 B reserved)
+  double2 *ltab = reinterpret_cast<double2 *>(smem + 256);     // 64 entries
+  float *Pall = reinterpret_cast<float *>(smem + 256 + 1024);
   const int wave = __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6));
   const int lane = threadIdx.x & 63;
-  // per wave: the two A-operand planes; between matrix passes the same space holds the 36 tile accumulators of every lane
-  // (they would otherwise be live across the column pass: 36 registers the register FFT and the operand ring need)
-  constexpr int WSP = kFm2WaveFloats;
-  float *Pl = Pall + (size_t) wave * WSP;
+  float *Pl = Pall + (size_t) wave * kFm2WaveFloats;
   float *Dpark = Pl + lane;
 
-  for (int t = threadIdx.x; t < N; t += blockDim.x)
-  {
-    const float2 w = a.tw[t];
-    tcos[t + (t >> 5)] = w.x;
-    tcos[NT + t + (t >> 5)] = w.y;
-  }
   if (threadIdx.x < kFm2Rows)
     rankW[threadIdx.x] = -1;
   for (int t = threadIdx.x; t < 64; t += blockDim.x)
@@ -119,24 +104,12 @@ __global__ __launch_bounds__(256, BIOEM_FM2_WAVES) void k_compare_fastm2(const C
                                                        (int) (M * sizeof(float2)), 0x00020000);
   const auto rsrcC = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(const_cast<float2 *>(a.conv + (size_t) oc * M)), 0,
                                                        (int) (M * sizeof(float2)), 0x00020000);
-
-#if BIOEM_FM2_BTAB
   const auto rsrcB = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(const_cast<float *>(a.btab)), 0,
-                                                       (int) (((Hlim0(a.H, NYQ) + 31) / 32) * 16 * 768), 0x00020000);
-#endif
+                                                       (int) (fastm2_btab_floats(a.H, NYQ) * sizeof(float)), 0x00020000);
   const int hh = lane >> 5, c32 = lane & 31;
   // matrix-pass lane constants: tile row / column jn = lane % 16, k index kq = lane / 16 = (column of the pair, re | im)
   const int jn = lane & 15, kq = lane >> 4;
-  const int part = kq & 1, kcol = kq >> 1;
-  const float *Arow = Pl + part * PLANE + jn * PS + kcol; // A[row 16 rt + jn][k]: Arow[rt * 16 * PS + 2 ks]
-  const float *Btab = tcos + part * NT;
-  int stepB[3];
-#pragma unroll
-  for (int ct = 0; ct < 3; ct++)
-  {
-    const int dy = 16 * ct + jn - WD;
-    stepB[ct] = dy < 0 ? dy + N : dy;
-  }
+  const float *Arow = Pl + (kq & 1) * PLANE + jn * PS + (kq >> 1); // A[row 16 rt + jn][k]: Arow[rt * 16 * PS + 2 ks]
 #pragma unroll
   for (int i = 0; i < 36; i++)
     Dpark[i * 64] = 0.f;
@@ -144,7 +117,6 @@ __global__ __launch_bounds__(256, BIOEM_FM2_WAVES) void k_compare_fastm2(const C
   const int Hlim = NYQ ? H - 1 : H; // columns of the passes (the Nyquist column of 128^2 / 256^2 comes from k_nyquist_rows)
   const int npass = (Hlim + 31) / 32;
   const int nS = (N1 + 1) >> 1; // steps: k1 pairs
-  const int ttotal = R2 * nS;
   const unsigned rowbytes = (unsigned) H * 16u;
   const unsigned halfoff = (unsigned) hh * (unsigned) R2 * rowbytes; // the high half reads k1 = 2 s + 1: R2 row pairs on
   u32x4 rf[RD], rc[RD];
@@ -165,9 +137,9 @@ __global__ __launch_bounds__(256, BIOEM_FM2_WAVES) void k_compare_fastm2(const C
     const int kyn = ky + 32 < H ? ky + 32 : H - 1;
     const unsigned laneoff_next = (unsigned) kyn * 16u + halfoff;
     const bool has_next = cp + 1 < npass;
-    float Tr[kFm2Acc], Ti[kFm2Acc];
+    float Tr[NACC], Ti[NACC];
 #pragma unroll
-    for (int d = 0; d < kFm2Acc; d++)
+    for (int d = 0; d < NACC; d++)
     {
       Tr[d] = 0.f;
       Ti[d] = 0.f;
@@ -176,8 +148,8 @@ __global__ __launch_bounds__(256, BIOEM_FM2_WAVES) void k_compare_fastm2(const C
     for (int s = 0; s < nS; s++)
     {
       float xr[R], xi[R];
-      // w_N^(8 k1) of this lane's k1 = 2 s + hh
-      const float2 rot = a.tw[(8 * (2 * s + hh)) % N];
+      // w_N^((R / 2) k1) of this lane's k1 = 2 s + hh
+      const float2 rot = a.tw[(R2 * (2 * s + hh)) % N];
 #pragma unroll
       for (int k2p = 0; k2p < R2; k2p++)
       {
@@ -208,50 +180,52 @@ __global__ __launch_bounds__(256, BIOEM_FM2_WAVES) void k_compare_fastm2(const C
         __builtin_amdgcn_sched_barrier(0);
       }
       FFT_RUN(xr, xi);
-      // the eight outputs that the HIGH half will fold: times w_N^(8 k1); then the exchange between the halves
+      // the R / 2 outputs that the HIGH half will fold: times w_N^((R / 2) k1); then the exchange between the halves
 #pragma unroll
-      for (int j = 0; j < 8; j++)
+      for (int j = 0; j < R2; j++)
       {
-        constexpr int P0 = ((-WD) % R + R) % R;
-        const int pp = (P0 + j) % R, qq = (pp + 8) % R;
-        const float yr = xr[qq], yi = xi[qq];
+        const int pp = (P0 + j) % R, qq = (pp + R2) % R;
+        const float yr = xr[FFT_OUT(qq)], yi = xi[FFT_OUT(qq)];
         const float zr = fmaf(-yi, rot.y, yr * rot.x);
         const float zi = fmaf(yi, rot.x, yr * rot.y);
-        const u32x2s sr = __builtin_amdgcn_permlane32_swap(__float_as_uint(xr[pp]), __float_as_uint(zr), false, false);
-        const u32x2s si = __builtin_amdgcn_permlane32_swap(__float_as_uint(xi[pp]), __float_as_uint(zi), false, false);
-        xr[pp] = __uint_as_float(sr.x); // k1 = 2 s:     residue pp (low half) | pp + 8 (high half)
-        xr[qq] = __uint_as_float(sr.y); // k1 = 2 s + 1
-        xi[pp] = __uint_as_float(si.x);
-        xi[qq] = __uint_as_float(si.y);
+        const u32x2s sr = __builtin_amdgcn_permlane32_swap(__float_as_uint(xr[FFT_OUT(pp)]), __float_as_uint(zr), false, false);
+        const u32x2s si = __builtin_amdgcn_permlane32_swap(__float_as_uint(xi[FFT_OUT(pp)]), __float_as_uint(zi), false, false);
+        xr[FFT_OUT(pp)] = __uint_as_float(sr.x); // k1 = 2 s:     residue pp (low half) | pp + R / 2 (high half)
+        xr[FFT_OUT(qq)] = __uint_as_float(sr.y); // k1 = 2 s + 1
+        xi[FFT_OUT(pp)] = __uint_as_float(si.x);
+        xi[FFT_OUT(qq)] = __uint_as_float(si.y);
       }
       // recombination: T[a] += wE[a] E_j + wO[a] O_j, twiddles of the LOW rows (wave-uniform), four accumulators at a time
-      const const_float4_ptr twk = (const_float4_ptr) (unsigned long long) (reinterpret_cast<const float4 *>(a.twk) + (size_t) s * kFm2Acc);
+      const const_float4_ptr twk = (const_float4_ptr) (unsigned long long) (reinterpret_cast<const float4 *>(a.twk) + (size_t) s * NACC);
 #pragma unroll
-      for (int a0 = 0; a0 < kFm2Acc; a0 += 4)
+      for (int a0 = 0; a0 < NACC; a0 += 4)
       {
         float4 wk[4];
 #pragma unroll
         for (int e = 0; e < 4; e++)
         {
-          wk[e] = make_float4(twk[a0 + e].x, twk[a0 + e].y, twk[a0 + e].z, twk[a0 + e].w);
+          const int ae = a0 + e < NACC ? a0 + e : NACC - 1;
+          wk[e] = make_float4(twk[ae].x, twk[ae].y, twk[ae].z, twk[ae].w);
         }
 #pragma unroll
         for (int e = 0; e < 4; e++)
         {
-          constexpr int P0 = ((-WD) % R + R) % R;
-          const int j = (a0 + e) & 7;
-          const int pp = (P0 + j) % R, qq = (pp + 8) % R;
-          float tr = Tr[a0 + e], ti = Ti[a0 + e];
-          tr = fmaf(xr[pp], wk[e].x, tr);
-          tr = fmaf(-xi[pp], wk[e].y, tr);
-          tr = fmaf(xr[qq], wk[e].z, tr);
-          tr = fmaf(-xi[qq], wk[e].w, tr);
-          ti = fmaf(xr[pp], wk[e].y, ti);
-          ti = fmaf(xi[pp], wk[e].x, ti);
-          ti = fmaf(xr[qq], wk[e].w, ti);
-          ti = fmaf(xi[qq], wk[e].z, ti);
-          Tr[a0 + e] = tr;
-          Ti[a0 + e] = ti;
+          if (a0 + e < NACC)
+          {
+            const int j = (a0 + e) % R2;
+            const int pp = (P0 + j) % R, qq = (pp + R2) % R;
+            float tr = Tr[a0 + e], ti = Ti[a0 + e];
+            tr = fmaf(xr[FFT_OUT(pp)], wk[e].x, tr);
+            tr = fmaf(-xi[FFT_OUT(pp)], wk[e].y, tr);
+            tr = fmaf(xr[FFT_OUT(qq)], wk[e].z, tr);
+            tr = fmaf(-xi[FFT_OUT(qq)], wk[e].w, tr);
+            ti = fmaf(xr[FFT_OUT(pp)], wk[e].y, ti);
+            ti = fmaf(xi[FFT_OUT(pp)], wk[e].x, ti);
+            ti = fmaf(xr[FFT_OUT(qq)], wk[e].w, ti);
+            ti = fmaf(xi[FFT_OUT(qq)], wk[e].z, ti);
+            Tr[a0 + e] = tr;
+            Ti[a0 + e] = ti;
+          }
         }
       }
     }
@@ -269,122 +243,64 @@ __global__ __launch_bounds__(256, BIOEM_FM2_WAVES) void k_compare_fastm2(const C
 #pragma unroll
         for (int i = 0; i < 4; i++)
           D[rt][ct][i] = Dpark[((rt * 3 + ct) * 4 + i) * 64];
-#if BIOEM_FM2_BTAB
-    static_assert(CX == 32, "the tabulated B operand takes the 32-column exchange");
     {
-      // B operand of k-step K = cp 16 + ks (columns 2 K, 2 K + 1), column tile ct, as this lane supplies it: tabulated
-      // on the host (it is the same matrix for every comparison), fetched through a ring PF k-steps ahead -- no index
-      // arithmetic, no LDS reads; the requests of the first PF k-steps are in flight while T moves into the planes
+      // B operand of k-step K = cp 16 + ks (columns 2 K, 2 K + 1), column tile ct, as this lane supplies it: fetched
+      // through a ring PF k-steps ahead -- the requests of the first PF k-steps fly while T moves into the planes
       constexpr int PF = 4;
       const unsigned soff0 = (unsigned) cp * 16u * 768u;
       float bq[PF][3];
-      const bool active = cp * 32 < Hlim;
       const int nks = min(16, (Hlim - cp * 32 + 1) >> 1);
-      if (active)
-      {
 #pragma unroll
-        for (int q = 0; q < PF; q++)
-#pragma unroll
-          for (int ct = 0; ct < 3; ct++)
-            bq[q][ct] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrcB, (unsigned) lane * 4u, soff0 + (unsigned) (q * 3 + ct) * 256u, 0));
-      }
-      WAVE_OR_BLOCK_SYNC(); // D is out of LDS
-#pragma unroll
-      for (int d = 0; d < kFm2Acc; d++)
-      {
-        const int m = (d >> 3) * 16 + (d & 7); // low-half row; the high half's row is 8 further
-        if (m + 8 < kFm2PlaneRows || hh == 0)
-        {
-          Pl[(m + 8 * hh) * PS + c32] = Tr[d] * wgt;
-          Pl[PLANE + (m + 8 * hh) * PS + c32] = -(Ti[d] * wgt);
-        }
-      }
-      WAVE_OR_BLOCK_SYNC();
-      if (active)
-      {
-#pragma unroll
-        for (int k4 = 0; k4 < 16; k4 += PF)
-        {
-          if (k4 < nks) // (k-steps beyond the last column pair of a chunk of PF multiply zeros)
-          {
-#pragma unroll
-            for (int q = 0; q < PF; q++)
-            {
-              const int ks = k4 + q;
-              float av[3], bv[3];
-#pragma unroll
-              for (int rt = 0; rt < 3; rt++)
-                av[rt] = Arow[rt * 16 * PS + 2 * ks];
-#pragma unroll
-              for (int ct = 0; ct < 3; ct++)
-                bv[ct] = bq[q][ct];
-              if (ks + PF < 16)
-              {
-#pragma unroll
-                for (int ct = 0; ct < 3; ct++)
-                  bq[q][ct] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrcB, (unsigned) lane * 4u, soff0 + (unsigned) ((ks + PF) * 3 + ct) * 256u, 0));
-              }
-#pragma unroll
-              for (int rt = 0; rt < 3; rt++)
-#pragma unroll
-                for (int ct = 0; ct < 3; ct++)
-                  D[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[rt], bv[ct], D[rt][ct], 0, 0, 0);
-            }
-          }
-        }
-      }
-    }
-#else
-#pragma unroll
-    for (int e = 0; e < 32 / CX; e++)
-    {
-      WAVE_OR_BLOCK_SYNC(); // the matrix pass of the previous columns has read its operands (pass start: D is out of LDS)
-      if (CX == 32 || (c32 >> 4) == e)
-      {
-#pragma unroll
-        for (int d = 0; d < kFm2Acc; d++)
-        {
-          const int m = (d >> 3) * 16 + (d & 7); // low-half row; the high half's row is 8 further
-          if (m + 8 < kFm2PlaneRows || hh == 0)
-          {
-            Pl[(m + 8 * hh) * PS + (c32 & (CX - 1))] = Tr[d] * wgt;
-            Pl[PLANE + (m + 8 * hh) * PS + (c32 & (CX - 1))] = -(Ti[d] * wgt);
-          }
-        }
-      }
-      WAVE_OR_BLOCK_SYNC();
-      const int ky0 = cp * 32 + e * CX;
-      if (ky0 < Hlim)
-      {
-        const int nks = min(CX / 2, (Hlim - ky0 + 1) >> 1); // column pairs that hold columns (a last odd column's partner is zero)
-        unsigned idx[3];
+      for (int q = 0; q < PF; q++)
 #pragma unroll
         for (int ct = 0; ct < 3; ct++)
-          idx[ct] = (unsigned) (((long long) (ky0 + kcol) * stepB[ct]) % N);
-#pragma unroll 2
-        for (int ks = 0; ks < nks; ks++)
+          bq[q][ct] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrcB, (unsigned) lane * 4u, soff0 + (unsigned) (q * 3 + ct) * 256u, 0));
+      WAVE_OR_BLOCK_SYNC(); // D is out of LDS
+#pragma unroll
+      for (int d = 0; d < NACC; d++)
+      {
+        const int m = (d / R2) * R + (d % R2); // low-half row; the high half's row is R / 2 further
+        if (m < kFm2PlaneRows)
         {
-          float av[3], bv[3];
-#pragma unroll
-          for (int rt = 0; rt < 3; rt++)
-            av[rt] = Arow[rt * 16 * PS + 2 * ks];
-#pragma unroll
-          for (int ct = 0; ct < 3; ct++)
+          if (m + R2 < kFm2PlaneRows || hh == 0)
           {
-            bv[ct] = Btab[idx[ct] + (idx[ct] >> 5)];
-            idx[ct] += 2u * (unsigned) stepB[ct];
-            idx[ct] = min(idx[ct], idx[ct] - (unsigned) N); // idx < 3 N: two wraps at most
-            idx[ct] = min(idx[ct], idx[ct] - (unsigned) N);
+            Pl[(m + R2 * hh) * PS + c32] = Tr[d] * wgt;
+            Pl[PLANE + (m + R2 * hh) * PS + c32] = -(Ti[d] * wgt);
           }
+        }
+      }
+      WAVE_OR_BLOCK_SYNC();
 #pragma unroll
-          for (int rt = 0; rt < 3; rt++)
+      for (int k4 = 0; k4 < 16; k4 += PF)
+      {
+        if (k4 < nks) // (k-steps beyond the last column pair of a chunk of PF multiply zeros)
+        {
+#pragma unroll
+          for (int q = 0; q < PF; q++)
+          {
+            const int ks = k4 + q;
+            float av[3], bv[3];
+#pragma unroll
+            for (int rt = 0; rt < 3; rt++)
+              av[rt] = Arow[rt * 16 * PS + 2 * ks];
 #pragma unroll
             for (int ct = 0; ct < 3; ct++)
-              D[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[rt], bv[ct], D[rt][ct], 0, 0, 0);
+              bv[ct] = bq[q][ct];
+            if (ks + PF < 16)
+            {
+#pragma unroll
+              for (int ct = 0; ct < 3; ct++)
+                bq[q][ct] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrcB, (unsigned) lane * 4u, soff0 + (unsigned) ((ks + PF) * 3 + ct) * 256u, 0));
+            }
+#pragma unroll
+            for (int rt = 0; rt < 3; rt++)
+#pragma unroll
+              for (int ct = 0; ct < 3; ct++)
+                D[rt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[rt], bv[ct], D[rt][ct], 0, 0, 0);
+          }
         }
       }
     }
-#endif
     WAVE_OR_BLOCK_SYNC(); // the planes are read: their space takes the accumulators until the next matrix pass
 #pragma unroll
     for (int rt = 0; rt < 3; rt++)
@@ -394,8 +310,6 @@ __global__ __launch_bounds__(256, BIOEM_FM2_WAVES) void k_compare_fastm2(const C
         for (int i = 0; i < 4; i++)
           Dpark[((rt * 3 + ct) * 4 + i) * 64] = D[rt][ct][i];
   }
-  // (the tile accumulators stay parked: every posterior batch fetches its own -- 36 values live across the batches'
-  // slow-path call sites spilled 22 registers)
 
   // tile element (rt, ct, i) of this lane: window row m = 16 rt + 4 kq + i, window column n = 16 ct + jn
   const int mD = a.maxD;

@@ -110,11 +110,10 @@ size_t fastm_lds_bytes(int N)
   // resting place of the 16 tile accumulators
   return (size_t) 2 * fastm_table_floats(N) * 4 + 128 + 1024 + (size_t) 4 * 2 * 32 * 33 * 4 + (size_t) 4 * 16 * 64 * 4;
 }
-size_t fastm2_lds_bytes(int N)
-{ // cos / sin planes of the twiddle table (padded), window ranks, log table, per wave the two 48 x 17 float planes /
-  // the resting place of the 36 tile accumulators
+size_t fastm2_lds_bytes()
+{ // window ranks, log table, per wave the two 47 x 33 float planes / the resting place of the 36 tile accumulators
   // (+ 256 B: the operand read of plane row 47, which holds no window row, may run past the last wave's planes)
-  return (size_t) 2 * fastm_table_floats(N) * 4 + 256 + 1024 + (size_t) 4 * kFm2WaveFloats * 4 + 256;
+  return (size_t) 256 + 1024 + (size_t) 4 * kFm2WaveFloats * 4 + 256;
 }
 size_t wide2_lds_bytes(int N, int R, int rows2, int ts, int nw = 4)
 { // tables (twiddles, visiting ranks, log table, wave results, posterior constants) + max(one FFT-output slot per wave, T block)
@@ -459,24 +458,31 @@ KernelPlan plan_kernels(int N, int maxD, int grid, int algo)
   // 1. one window kernel
   if (fitsWindow && plan_window_kernel(P, N, H, winD, true))
     return P;
-  // 2a. 33..47 rows at unit stride, N a multiple of 16: k_compare_fastm2 (one wave per comparison, rows split over the
-  //     half-waves; round 4: 224^2 +-20 px against k_compare_wide2<16, 11, 2>)
-  if (N % 16 == 0 && N >= 64 && symmetric && P.gs == 1 && P.nd >= 33 && P.nd <= 2 * kFm2WD + 1 && !getenv("BIOEM_NO_FASTM2") &&
+  // 2a. 33..47 rows at unit stride, N a multiple of 16 / 12 / 10 / 8: k_compare_fastm2 (one wave per comparison, rows split
+  //     over the half-waves; round 4: 224^2 +-20 px 24.8 -> 30.9 M/s against k_compare_wide2<16, 11, 2>).  The
+  //     longest length that divides N: the recombination costs 8 fused multiply-adds per accumulator and step whatever
+  //     the length, so fewer, longer steps win (per column and unit of N: 14 / 16 / 18 / 19 instructions at 16 / 12 / 10 / 8)
+  if (N >= 64 && symmetric && P.gs == 1 && P.nd >= 33 && P.nd <= 2 * kFm2WD + 1 && !getenv("BIOEM_NO_FASTM2") &&
       !getenv("BIOEM_FORCE_WIDE2"))
   {
     const bool nyq = BIOEM_NYQUIST_SPLIT && (N / 2) % 64 == 0;
-    if (const fast_kernel_t fn = find_kernel(KF_FASTM2, 16, nyq))
+    for (int R : {16, 12, 10, 8})
     {
+      if (N % R != 0)
+        continue;
+      const fast_kernel_t fn = find_kernel(KF_FASTM2, R, nyq);
+      if (!fn)
+        continue;
       P.family = KF_FASTM2;
       P.fastm2 = true;
       P.fn = fn;
-      P.fast = 8;
-      P.N1 = N / 16;
+      P.fast = R / 2;
+      P.N1 = N / R;
       P.nyq = nyq;
       P.nyqWD = mD <= 20 ? 20 : 31;
       if (nyq)
         P.winD = P.nyqWD; // sizes the Nyquist pre-kernel's tables
-      P.ldsBytes = fastm2_lds_bytes(N);
+      P.ldsBytes = fastm2_lds_bytes();
       return P;
     }
   }

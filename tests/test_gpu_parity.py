@@ -1080,6 +1080,27 @@ def test_wide2_kernel_against_oracle(N, maxD, grid, algo, monkeypatch):
         W.engine.close()
 
 
+@pytest.mark.parametrize("N,maxD", [(224, 20), (224, 16), (224, 23), (128, 20), (256, 21), (208, 18), (64, 16), (96, 22),
+                                    (160, 19), (336, 17), (512, 20), (240, 23)])
+@pytest.mark.parametrize("algo", [1, 2])
+def test_fastm2_kernel_against_oracle(N, maxD, algo):
+    """k_compare_fastm2 (33..47-row windows: rows split over the half-waves, 3 x 3 matrix tiles): both instantiations
+    (Nyquist split at 128 / 256 / 512), an odd number of 16-point sub-transforms (208 = 13 x 16, 240, 336: the high half of
+    the last step reads beyond the buffer), a partly filled last column pass (224, 96, 160), the narrowest and the widest
+    window of the family, ALGO 1 / 2."""
+    from bioem_amd.synthetic import Workload
+    nP, nO = 5, 7
+    W = Workload(N=N, nP=nP, nOrient=nO, nEnv=2, maxD=maxD, algo=algo, npts=300)
+    try:
+        assert W.engine.kernel_signature == "k_compare_fastm2<16, %s>" % ("true" if (N // 2) % 64 == 0 else "false")
+        sel = list(range(nP))
+        want, const = oracle_on_workload(W, sel, nO, algo)
+        _, got = run_workload(W, 0, nO)
+        assert_workload_matches(got, want, const, sel)
+    finally:
+        W.engine.close()
+
+
 def _random_configs(n, seed):
     """Seeded random (N, maxD, grid, algo, nEnv, nP, nO) tuples over the whole configuration space of the comparison
     kernels: every register-FFT length, the Nyquist split, window templates, row strides, tiles, the generic path."""
