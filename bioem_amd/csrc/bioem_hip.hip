@@ -1053,16 +1053,16 @@ static int create_impl(bioem_hip_handle *out, int device, const bioem_hip_param_
     HIP_CHECK(h, hipMemcpy(h->dTwk2, t2.data(), sizeof(float2) * t2.size(), hipMemcpyHostToDevice));
   }
   if (h->fastm2)
-  { // recombination twiddles of k_compare_fastm2<R>: [k1 pair s][accumulator a = (R / 2) g + j] = {w^(dx 2s), w^(dx (2s+1))} for
-    // the LOW-half row dx = R g + j - 23 (the high half folds the rows R / 2 further with the same numbers); zero for a k1
-    // beyond N1 - 1 (rows outside the displacement list are masked by their rank in the kernel)
-    const int Rl = 2 * h->fast, nAcc = fastm2_acc(Rl);
+  { // recombination twiddles of k_compare_fastm2<R, NYQ, GS>: [k1 pair s][accumulator a = OFF g + j] = {w^(dx 2s), w^(dx (2s+1))}
+    // for the LOW-half row dx = (2 OFF g + j - 23) GS (the high half folds the rows OFF further with the same numbers); zero
+    // for a k1 beyond N1 - 1 (rows outside the displacement list are masked by their rank in the kernel)
+    const int Rl = 2 * h->fast, off = fastm2_off(Rl, h->gs), nAcc = fastm2_acc(Rl, h->gs);
     const int nS = (h->N1 + 1) / 2;
     std::vector<float4> t4((size_t) nS * nAcc, make_float4(0.f, 0.f, 0.f, 0.f));
     for (int s2 = 0; s2 < nS; s2++)
       for (int ac = 0; ac < nAcc; ac++)
       {
-        const long long dx = Rl * (ac / (Rl / 2)) + (ac % (Rl / 2)) - kFm2WD;
+        const long long dx = (long long) (2 * off * (ac / off) + (ac % off) - kFm2WD) * h->gs;
         float w[4] = {0.f, 0.f, 0.f, 0.f};
         for (int e = 0; e < 2; e++)
         {
@@ -1078,13 +1078,13 @@ static int create_impl(bioem_hip_handle *out, int device, const bioem_hip_param_
     HIP_CHECK(h, hipMalloc(&h->dTwk2, sizeof(float4) * t4.size()));
     HIP_CHECK(h, hipMemcpy(h->dTwk2, t4.data(), sizeof(float4) * t4.size(), hipMemcpyHostToDevice));
     // B operand of the matrix pass: lane l of k-step K, column tile ct supplies (l / 16 odd ? sin : cos)(2 pi ky dy / N),
-    // ky = 2 K + l / 32, dy = 16 ct + l % 16 - 23 -- the float twiddles exp(2 pi i k / N) every kernel uses
+    // ky = 2 K + l / 32, dy = (16 ct + l % 16 - 23) GS -- the float twiddles exp(2 pi i k / N) every kernel uses
     std::vector<float> bt(fastm2_btab_floats(h->H, h->nyq));
     for (size_t K = 0; K < bt.size() / 192; K++)
       for (int ct = 0; ct < 3; ct++)
         for (int l = 0; l < 64; l++)
         {
-          const long long ky = 2 * (long long) K + (l >> 5), dy = 16 * ct + (l & 15) - kFm2WD;
+          const long long ky = 2 * (long long) K + (l >> 5), dy = (long long) (16 * ct + (l & 15) - kFm2WD) * h->gs;
           const double ang = 2.0 * M_PI * (double) (((ky * dy) % N + N) % N) / (double) N;
           bt[(K * 3 + ct) * 64 + l] = ((l >> 4) & 1) ? (float) sin(ang) : (float) cos(ang);
         }
@@ -2073,7 +2073,7 @@ const char *bioem_hip_kernel_signature(bioem_hip_handle h)
       snprintf(buf, sizeof(buf), h->w2NW == 8 ? "k_compare_wide2<%d, %d, %d, %s, 1, 8>" : "k_compare_wide2<%d, %d, %d, %s>",
                2 * h->fast, h->w2NRW, h->w2NBLK, nq);
   else if (h->fastm2)
-    snprintf(buf, sizeof(buf), "k_compare_fastm2<%d, %s>", 2 * h->fast, nq);
+    snprintf(buf, sizeof(buf), "k_compare_fastm2<%d, %s, %d>", 2 * h->fast, nq, h->gs);
   else if (h->fastm)
     snprintf(buf, sizeof(buf), "k_compare_fastm<%d, %d, %s, %d>", h->winD, 2 * h->fast, nq, h->gs);
   else if (h->fast)

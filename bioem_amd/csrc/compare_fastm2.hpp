@@ -30,7 +30,8 @@ namespace
 // v_mfma_f32_16x16x4_f32 (K = 2 columns x {re, im}), 36 accumulator registers that never leave the register file; T
 // reaches the A-operand planes in LDS 16 columns at a time (6.4 KiB per wave).  One 32 x 32 x 2 tile pair per axis would
 // cost 64 accumulators and 1.8x the matrix-pipe time.
-// Rows m = 0..46 hold dx = m - 23 for EVERY window of the family (+-16 ... +-23 px): rows outside the displacement list
+// Rows m = 0..46 hold dx = (m - 23) GS for EVERY window of the family (+-16 ... +-23 rows at stride GS = 1..4 pixels): rows
+// outside the displacement list
 // get zero twiddles and a rank of -1 -- the cost does not depend on the width inside the family (48 rows either way).
 // R = 16, or 12 / 10 / 8 where 16 does not divide N (rows 8 / 6 / 5 / 4 apart pair up; 3 / 4 / 5 / 6 groups of R rows,
 // 24 or 25 accumulators); an odd N1 = N / R leaves the high half of the last step reading beyond the buffer
@@ -46,9 +47,18 @@ constexpr int kFm2PlaneRows = 47; // row 47 holds no window row: neither written
 // LDS floats per wave: the two A-operand planes (12.1 KiB); between matrix passes the same space holds the 36 tile
 // accumulators of every lane
 constexpr int kFm2WaveFloats = 36 * 64 > 2 * kFm2PlaneRows * kFm2PS ? 36 * 64 : 2 * kFm2PlaneRows * kFm2PS;
-// groups of R rows and complex accumulators per lane for a register FFT of length R: rows m = R g + (R / 2) half + j
-__host__ __device__ constexpr int fastm2_groups(int R) { return (2 * kFm2WD + R) / R; }
-__host__ __device__ constexpr int fastm2_acc(int R) { return fastm2_groups(R) * (R / 2); }
+// Rows OFF apart pair up: OFF = the smallest row distance whose pixel distance OFF GS is R / 2 mod R (8 / 6 / 5 / 4 rows for
+// R = 16 / 12 / 10 / 8 at unit stride; 4, 8, 2 rows for R = 16 at stride 2, 3, 4).  The low half of the wave owns the
+// rows m = 2 OFF g + j (j < OFF), the high half the rows OFF further; groups and complex accumulators per lane:
+__host__ __device__ constexpr int fastm2_off(int R, int GS)
+{
+  for (int o = 1; o <= R; o++)
+    if ((o * GS) % R == R / 2)
+      return o;
+  return 0;
+}
+__host__ __device__ constexpr int fastm2_groups(int R, int GS) { return (2 * kFm2WD + 2 * fastm2_off(R, GS)) / (2 * fastm2_off(R, GS)); }
+__host__ __device__ constexpr int fastm2_acc(int R, int GS) { return fastm2_groups(R, GS) * fastm2_off(R, GS); }
 // the B operand of the matrix pass -- (lane / 16 odd ? sin : cos)(2 pi ky dy / N), ky = 2 K + lane / 32, dy = 16 ct + lane
 // % 16 - 23 -- is the same matrix for every comparison: tabulated on the host, [column pass][16 k-steps][3 column
 // tiles][64 lanes] floats (index arithmetic on the LDS twiddle table cost 30 vector instructions per k-step and a
@@ -56,19 +66,20 @@ __host__ __device__ constexpr int fastm2_acc(int R) { return fastm2_groups(R) * 
 __host__ __device__ constexpr int Hlim0(int H, bool nyq) { return nyq ? H - 1 : H; }
 __host__ __device__ constexpr size_t fastm2_btab_floats(int H, bool nyq) { return (size_t) ((Hlim0(H, nyq) + 31) / 32) * 16 * 3 * 64; }
 
-// recombination twiddles of the low rows, [k1 pair s][accumulator a = (R / 2) g + j] = {w^(dx 2s), w^(dx (2s+1))},
-// dx = R g + j - WD
+// recombination twiddles of the low rows, [k1 pair s][accumulator a = OFF g + j] = {w^(dx 2s), w^(dx (2s+1))},
+// dx = (2 OFF g + j - WD) GS
 typedef const float4 __attribute__((address_space(4))) *const_float4_ptr;
 
-template <int R, bool NYQ>
+template <int R, bool NYQ, int GS>
 __global__ __launch_bounds__(256, 3) void k_compare_fastm2(const CompareArgs a)
 {
   static_assert(R == 16 || R == 12 || R == 10 || R == 8, "register FFT of 16, 12, 10 or 8 points");
+  constexpr int OFF = fastm2_off(R, GS);    // rows between the halves' rows
+  static_assert(OFF > 0, "no row distance pairs up at this stride");
   constexpr int WD = kFm2WD, NWR = 2 * WD + 1;
-  constexpr int R2 = R / 2;                 // row pairs of a step = rows between the halves' rows
+  constexpr int R2 = R / 2;                 // row pairs of a step
   constexpr int RD = (R2 % 4 == 0) ? 4 : (R2 % 3 == 0) ? 3 : R2; // operand ring depth (divides R2)
-  constexpr int NACC = fastm2_acc(R);       // 24 (25 for R = 10)
-  constexpr int P0 = ((-WD) % R + R) % R;   // residue of window row 0
+  constexpr int NACC = fastm2_acc(R, GS);   // 24 (25 for R = 10)
   constexpr int PS = kFm2PS, PLANE = kFm2PlaneRows * PS;
   extern __shared__ __align__(16) unsigned char smem[];
   const int N = a.N, H = a.H, N1 = a.N1;
@@ -87,7 +98,7 @@ __global__ __launch_bounds__(256, 3) void k_compare_fastm2(const CompareArgs a)
   __syncthreads();
   for (int t = threadIdx.x; t < a.nd; t += blockDim.x)
   {
-    const int m = a.disp[t] + WD;
+    const int m = a.disp[t] / GS + WD;
     if (m >= 0 && m < NWR)
       rankW[m] = t;
   }
@@ -148,8 +159,8 @@ __global__ __launch_bounds__(256, 3) void k_compare_fastm2(const CompareArgs a)
     for (int s = 0; s < nS; s++)
     {
       float xr[R], xi[R];
-      // w_N^((R / 2) k1) of this lane's k1 = 2 s + hh
-      const float2 rot = a.tw[(R2 * (2 * s + hh)) % N];
+      // w_N^(OFF GS k1) of this lane's k1 = 2 s + hh: the high half's rows are OFF GS pixels further
+      const float2 rot = a.tw[(OFF * GS * (2 * s + hh)) % N];
 #pragma unroll
       for (int k2p = 0; k2p < R2; k2p++)
       {
@@ -180,11 +191,11 @@ __global__ __launch_bounds__(256, 3) void k_compare_fastm2(const CompareArgs a)
         __builtin_amdgcn_sched_barrier(0);
       }
       FFT_RUN(xr, xi);
-      // the R / 2 outputs that the HIGH half will fold: times w_N^((R / 2) k1); then the exchange between the halves
+      // the OFF outputs that the HIGH half will fold: times w_N^(OFF GS k1); then the exchange between the halves
 #pragma unroll
-      for (int j = 0; j < R2; j++)
+      for (int j = 0; j < OFF; j++)
       {
-        const int pp = (P0 + j) % R, qq = (pp + R2) % R;
+        const int pp = ((((j - WD) * GS) % R) + R) % R, qq = (pp + R2) % R; // residues of row j and of row j + OFF
         const float yr = xr[FFT_OUT(qq)], yi = xi[FFT_OUT(qq)];
         const float zr = fmaf(-yi, rot.y, yr * rot.x);
         const float zi = fmaf(yi, rot.x, yr * rot.y);
@@ -212,8 +223,8 @@ __global__ __launch_bounds__(256, 3) void k_compare_fastm2(const CompareArgs a)
         {
           if (a0 + e < NACC)
           {
-            const int j = (a0 + e) % R2;
-            const int pp = (P0 + j) % R, qq = (pp + R2) % R;
+            const int j = (a0 + e) % OFF;
+            const int pp = ((((j - WD) * GS) % R) + R) % R, qq = (pp + R2) % R;
             float tr = Tr[a0 + e], ti = Ti[a0 + e];
             tr = fmaf(xr[FFT_OUT(pp)], wk[e].x, tr);
             tr = fmaf(-xi[FFT_OUT(pp)], wk[e].y, tr);
@@ -259,13 +270,13 @@ __global__ __launch_bounds__(256, 3) void k_compare_fastm2(const CompareArgs a)
 #pragma unroll
       for (int d = 0; d < NACC; d++)
       {
-        const int m = (d / R2) * R + (d % R2); // low-half row; the high half's row is R / 2 further
+        const int m = (d / OFF) * 2 * OFF + (d % OFF); // low-half row; the high half's row is OFF further
         if (m < kFm2PlaneRows)
         {
-          if (m + R2 < kFm2PlaneRows || hh == 0)
+          if (m + OFF < kFm2PlaneRows || hh == 0)
           {
-            Pl[(m + R2 * hh) * PS + c32] = Tr[d] * wgt;
-            Pl[PLANE + (m + R2 * hh) * PS + c32] = -(Ti[d] * wgt);
+            Pl[(m + OFF * hh) * PS + c32] = Tr[d] * wgt;
+            Pl[PLANE + (m + OFF * hh) * PS + c32] = -(Ti[d] * wgt);
           }
         }
       }
@@ -312,7 +323,7 @@ __global__ __launch_bounds__(256, 3) void k_compare_fastm2(const CompareArgs a)
   }
 
   // tile element (rt, ct, i) of this lane: window row m = 16 rt + 4 kq + i, window column n = 16 ct + jn
-  const int mD = a.maxD;
+  const int mD = a.maxD / GS;
   const double2 pc = a.postc[oc];
   const PostW pw = post_consts(a.pd.Ntotpi, N, a.params[oc], a.sumRef[p], a.sumsqRef[p], pc.x, pc.y);
   const float *tq = NYQ ? a.tnyq + ((size_t) p * a.ldPart + oc) * (2 * a.nyqWD + 1) + a.nyqWD - WD : nullptr;
@@ -346,7 +357,7 @@ __global__ __launch_bounds__(256, 3) void k_compare_fastm2(const CompareArgs a)
       {
         float v = Dpark[(rt * 12 + ct * 4 + i) * 64];
         if (NYQ)
-          v = fmaf(((16 * ct + jn - WD) & 1) ? -1.f : 1.f, nq, v);
+          v = fmaf((((16 * ct + jn - WD) * GS) & 1) ? -1.f : 1.f, nq, v);
         accv[i * 3 + ct] = v;
         okv[i * 3 + ct] = rk >= 0 && rankn[ct] >= 0;
         idv[i * 3 + ct] = rk * a.nd + rankn[ct];

@@ -50,7 +50,7 @@ const KernelEntry kSlimTable[] = {
     {KF_FASTM, {BIOEM_SLIM_FASTM, 0, 0}, reinterpret_cast<const void *>(k_compare_fastm<BIOEM_SLIM_FASTM>)},
 #endif
 #ifdef BIOEM_SLIM_FASTM2
-    {KF_FASTM2, {BIOEM_SLIM_FASTM2, 0, 0, 0, 0}, reinterpret_cast<const void *>(k_compare_fastm2<BIOEM_SLIM_FASTM2>)},
+    {KF_FASTM2, {BIOEM_SLIM_FASTM2, 0, 0, 0}, reinterpret_cast<const void *>(k_compare_fastm2<BIOEM_SLIM_FASTM2>)},
 #endif
 #ifdef BIOEM_SLIM_W2
     {KF_WIDE2, {BIOEM_SLIM_W2}, reinterpret_cast<const void *>(k_compare_wide2<BIOEM_SLIM_W2>)},
@@ -462,7 +462,8 @@ KernelPlan plan_kernels(int N, int maxD, int grid, int algo)
   //     over the half-waves; round 4: 224^2 +-20 px 24.8 -> 30.9 M/s against k_compare_wide2<16, 11, 2>).  The
   //     longest length that divides N: the recombination costs 8 fused multiply-adds per accumulator and step whatever
   //     the length, so fewer, longer steps win (per column and unit of N: 14 / 16 / 18 / 19 instructions at 16 / 12 / 10 / 8)
-  if (N >= 64 && symmetric && P.gs == 1 && P.nd >= 33 && P.nd <= 2 * kFm2WD + 1 && !getenv("BIOEM_NO_FASTM2") &&
+  //     Row strides 2..4 (a coarse DISPLACE_CENTER grid) with the 16-point kernel: rows 4 / 8 / 2 apart pair up.
+  if (N >= 64 && symmetric && P.nd >= 33 && P.nd <= 2 * kFm2WD + 1 && !getenv("BIOEM_NO_FASTM2") &&
       !getenv("BIOEM_FORCE_WIDE2"))
   {
     const bool nyq = BIOEM_NYQUIST_SPLIT && (N / 2) % 64 == 0;
@@ -470,7 +471,7 @@ KernelPlan plan_kernels(int N, int maxD, int grid, int algo)
     {
       if (N % R != 0)
         continue;
-      const fast_kernel_t fn = find_kernel(KF_FASTM2, R, nyq);
+      const fast_kernel_t fn = find_kernel(KF_FASTM2, R, nyq, P.gs);
       if (!fn)
         continue;
       P.family = KF_FASTM2;
@@ -550,7 +551,7 @@ void plan_signature(const KernelPlan &P, char *buf, size_t cap)
                2 * P.fast, P.w2NRW, P.w2NBLK, nq);
     break;
   case KF_FASTM: snprintf(buf, cap, "k_compare_fastm<%d, %d, %s, %d>", P.winD, 2 * P.fast, nq, P.gs); break;
-  case KF_FASTM2: snprintf(buf, cap, "k_compare_fastm2<%d, %s>", 2 * P.fast, nq); break;
+  case KF_FASTM2: snprintf(buf, cap, "k_compare_fastm2<%d, %s, %d>", 2 * P.fast, nq, P.gs); break;
   case KF_FAST: snprintf(buf, cap, "k_compare_fast<%d, %d, %s, %d>", P.winD, 2 * P.fast, nq, P.gs); break;
   case KF_ODDFFT: snprintf(buf, cap, "k_compare_oddfft<%d, %d>", P.winD, P.oddR); break;
   case KF_ROWS: snprintf(buf, cap, "k_compare_rows<%d, %d>", P.winD, P.gs); break;

@@ -6,6 +6,6 @@
 #include "compare_fast.hpp"
 #include "compare_fastm.hpp"
 #include "compare_fastm2.hpp"
-#define K_FASTM2(R, NYQ) {KF_FASTM2, {R, NYQ, 0, 0, 0, 0}, reinterpret_cast<const void *>(k_compare_fastm2<R, NYQ>)},
+#define K_FASTM2(R, NYQ, GS) {KF_FASTM2, {R, NYQ, GS, 0, 0, 0}, reinterpret_cast<const void *>(k_compare_fastm2<R, NYQ, GS>)},
 #define BIOEM_FAMILY_FN bioem_kernels_fastm2
 #include "kernels_family.inc"

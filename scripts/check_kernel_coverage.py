@@ -34,7 +34,7 @@ def main():
     if "--so" in sys.argv:
         so = sys.argv[sys.argv.index("--so") + 1]
     with tempfile.TemporaryDirectory() as d:
-        ks = cco.kernels_of(cco.extract_code_object(so, d))
+        ks = [k for co in cco.extract_code_objects(so, d) for k in cco.kernels_of(co)]  # one code object per translation unit
     names = cco.demangle([k.get("name", k.get("symbol", "?")) for k in ks])
     shipped = sorted({canon(cco.short(n)) for n in names if re.match(r".*k_(compare|nyquist)", n)})
     ran = {canon(ln) for ln in open(log) if ln.strip()}

@@ -12,8 +12,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 # instantiations no shape of the snapshot selected when it was taken, added as spill-free stand-ins for the dropped
 # 32-point kernels of the same rule (scripts/kernel_table_drop.txt)
-EXTRA = ["k_compare_wide2<16, 11, 4, true, 2, 8>", "k_compare_wide2<16, 11, 4, true, 2, 4>",
-         "k_compare_wide2<16, 24, 2, true, 2, 4>"]
+EXTRA = ["k_compare_wide2<16, 11, 4, true, 2, 8>", "k_compare_wide2<16, 24, 2, true, 2, 4>"]
 
 
 def entry(sig):

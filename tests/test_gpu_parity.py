@@ -1080,19 +1080,26 @@ def test_wide2_kernel_against_oracle(N, maxD, grid, algo, monkeypatch):
         W.engine.close()
 
 
-@pytest.mark.parametrize("N,maxD", [(224, 20), (224, 16), (224, 23), (128, 20), (256, 21), (208, 18), (64, 16), (96, 22),
-                                    (160, 19), (336, 17), (512, 20), (240, 23)])
+@pytest.mark.parametrize("N,maxD,grid", [(224, 20, 1), (224, 16, 1), (224, 23, 1), (128, 20, 1), (256, 21, 1), (208, 18, 1),
+                                         (64, 16, 1), (96, 22, 1), (160, 19, 1), (336, 17, 1), (512, 20, 1), (240, 23, 1),
+                                         # register FFTs of 12 / 10 / 8 points where 16 does not divide N
+                                         (180, 17, 1), (300, 20, 1), (200, 20, 1), (250, 16, 1), (248, 23, 1), (88, 18, 1),
+                                         # row strides 2 / 3 / 4 (rows 4 / 8 / 2 apart pair up), also with the Nyquist split
+                                         (224, 40, 2), (224, 51, 3), (224, 80, 4), (256, 44, 2), (128, 48, 3), (256, 68, 4),
+                                         (208, 36, 2)])
 @pytest.mark.parametrize("algo", [1, 2])
-def test_fastm2_kernel_against_oracle(N, maxD, algo):
-    """k_compare_fastm2 (33..47-row windows: rows split over the half-waves, 3 x 3 matrix tiles): both instantiations
-    (Nyquist split at 128 / 256 / 512), an odd number of 16-point sub-transforms (208 = 13 x 16, 240, 336: the high half of
-    the last step reads beyond the buffer), a partly filled last column pass (224, 96, 160), the narrowest and the widest
-    window of the family, ALGO 1 / 2."""
+def test_fastm2_kernel_against_oracle(N, maxD, grid, algo):
+    """k_compare_fastm2 (33..47-row windows: rows split over the half-waves, 3 x 3 matrix tiles): every instantiation --
+    the Nyquist split (128 / 256 / 512), register FFTs of 16 / 12 / 10 / 8 points, row strides 1..4 --, an odd number of
+    sub-transforms (208 = 13 x 16, 240, 336, 200 = 25 x 8 ...: the high half of the last step reads beyond the buffer), a
+    partly filled last column pass, the narrowest and the widest window of the family, ALGO 1 / 2 (a stride that does
+    not divide maxD gives ALGO 1 an irregular set: that shape is not this kernel's)."""
     from bioem_amd.synthetic import Workload
     nP, nO = 5, 7
-    W = Workload(N=N, nP=nP, nOrient=nO, nEnv=2, maxD=maxD, algo=algo, npts=300)
+    W = Workload(N=N, nP=nP, nOrient=nO, nEnv=2, maxD=maxD, grid=grid, algo=algo, npts=300)
     try:
-        assert W.engine.kernel_signature == "k_compare_fastm2<16, %s>" % ("true" if (N // 2) % 64 == 0 else "false")
+        if maxD % grid == 0:
+            assert W.engine.kernel_name == "k_compare_fastm2"
         sel = list(range(nP))
         want, const = oracle_on_workload(W, sel, nO, algo)
         _, got = run_workload(W, 0, nO)

@@ -62,8 +62,10 @@ def test_headline_shapes():
     assert plan(L, 128, 10, 1, 1) == "k_compare_fast<10, 32, true, 1>"             # config 1 / 4 (Nyquist split)
     assert plan(L, 256, 10, 1, 1) == "k_compare_fast<10, 32, true, 1>"             # config 5
     assert plan(L, 224, 13, 1, 1) == "k_compare_fastm<13, 16, false, 1>"           # 27 rows: matrix-core window pass
-    assert plan(L, 224, 20, 1, 1) == "k_compare_fastm2<16, false>"                 # 41 rows: rows split over the half-waves
-    assert plan(L, 128, 16, 1, 2) == "k_compare_fastm2<16, true>"
+    assert plan(L, 224, 20, 1, 1) == "k_compare_fastm2<16, false, 1>"              # 41 rows: rows split over the half-waves
+    assert plan(L, 128, 16, 1, 2) == "k_compare_fastm2<16, true, 1>"
+    assert plan(L, 200, 20, 1, 1) == "k_compare_fastm2<10, false, 1>"              # 16 does not divide 200
+    assert plan(L, 224, 40, 2, 1) == "k_compare_fastm2<16, false, 2>"              # 41 rows at stride 2
     assert plan(L, 224, 40, 1, 1) == "k_compare_wide2<32, 21, 2, false>"           # tutorial production window
     assert plan(L, 225, 10, 1, 1) == "k_compare_oddfft<10, 25>"
     assert plan(L, 224, 120, 1, 1) == "rejected"                                   # maxD >= N / 2
