@@ -545,6 +545,12 @@ void dft_split(int N, int &A, int &B)
       A = d;
   B = N / A;
 }
+// the fast transform (r2c_fft.hpp) wherever it has the lengths; BIOEM_R2C=dft keeps the exact-DFT kernels (A/B, tests)
+bool r2c_use_fft(int N)
+{
+  const char *e = getenv("BIOEM_R2C");
+  return bioem_r2c_fft_supported(N) && !(e && !strcmp(e, "dft"));
+}
 bool dft_use_mfma(int N)
 {
   int A, B;
@@ -594,6 +600,8 @@ hipError_t launch_r2c(hipStream_t st, int nCU, const double *srcD, const float *
   const int H = N / 2 + 1;
   int A, B;
   dft_split(N, A, B);
+  if (r2c_use_fft(N))
+    return bioem_r2c_fft_launch(st, nCU, srcD, srcF, tempDen, NormDen, N, nImg, tw, rowSpec, out);
   if (dft_use_mfma(N))
   {
     // resident grids: as many blocks as the LDS of the device holds at once

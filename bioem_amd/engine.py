@@ -305,6 +305,18 @@ class Engine:
         self._chk(self.L.bioem_hip_reset_kernel_stats(self.h), "reset_kernel_stats")
 
 
+def r2c(images, device=0):
+    """fftwf_plan_dft_r2c_2d of a stack of square float images on the device (bioem_hip_r2c): [n, N, N] -> complex64
+    [n, N, N // 2 + 1], the kernels the projections and the particle maps go through."""
+    L = load_library()
+    images = np.ascontiguousarray(images, dtype=np.float32)
+    n, N, _ = images.shape
+    out = np.empty((n, N, N // 2 + 1), dtype=np.complex64)
+    if L.bioem_hip_r2c(device, N, n, _p(images), _p(out)):
+        raise RuntimeError("bioem_hip_r2c failed (N = %d, %d images)" % (N, n))
+    return out
+
+
 def merge_topk_host(cands):
     """K-way merge of per-shard candidate lists ([nMaps, K] each, shards in ascending orientation-block order)."""
     L = load_library()

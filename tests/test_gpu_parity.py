@@ -232,6 +232,33 @@ def test_device_projection_and_convolution(name):
     E.close()
 
 
+R2C_SIZES = [16, 20, 35, 44, 48, 50, 64, 75, 96, 100, 120, 128, 133, 144, 160, 180, 192, 200, 224, 225, 240, 256, 280, 288,
+             300, 304, 320, 360, 380, 400]
+
+
+@pytest.mark.parametrize("N", R2C_SIZES)
+def test_fast_r2c_against_numpy_and_the_exact_dft(N, monkeypatch):
+    """The r2c of projections and particle maps (r2c_fft.hpp: one split N = A * B, register FFTs of A and B points in
+    double) against numpy's double transform rounded to float -- what fftwf_plan_dft_r2c_2d (bioem.cpp:1848,
+    map.cpp:585) approximates -- and against the exact-DFT kernels of rounds 1-3 (BIOEM_R2C=dft): the same rounded
+    values but for a few last-bit flips.  Sizes: every sub-transform length 2...20 as A and as B, odd N, the BASELINE
+    sizes; 7 images so that a block's group of rows / columns runs over image boundaries and ends ragged."""
+    from bioem_amd import engine as eng
+    rng = np.random.default_rng(N)
+    img = rng.standard_normal((7, N, N)).astype(np.float32) + np.float32(0.3)
+    want = np.fft.rfft2(img.astype(np.float64))
+    monkeypatch.delenv("BIOEM_R2C", raising=False)
+    fast = eng.r2c(img)
+    scale = np.abs(want).max()
+    assert np.abs(fast - want).max() <= 1.5e-7 * scale          # float rounding of the exact result: 6e-8 of a value
+    monkeypatch.setenv("BIOEM_R2C", "dft")
+    slow = eng.r2c(img)
+    assert np.abs(slow - want).max() <= 1.5e-7 * scale
+    # bins that are zero in exact arithmetic (imaginary parts of the self-conjugate ones) are rounding noise in both
+    differ = np.count_nonzero(fast.view(np.float32) != slow.view(np.float32))
+    assert differ <= 0.02 * fast.size * 2, differ
+
+
 @pytest.mark.parametrize("name", ["g10_n64", "g9_n35_odd", "g7_n224", "g19_n200"])
 def test_fused_convolution_equals_the_two_kernel_one(name, monkeypatch):
     """k_convolve_sums (few particles) and k_convolve + k_parseval_ordered (many) are the same arithmetic in the same
