@@ -128,6 +128,8 @@ struct bioem_hip_ctx
   float2 *dCTF = nullptr;
   float *dCtfParam = nullptr;
   bioem_hip_model_point *dPts = nullptr;
+  double *dStamp = nullptr; // sphere footprints of the model (k_project_stamps), (2 iradMax + 1)^2 doubles per point
+  double modelRadius = 0.;  // max |point| of the model, Angstrom (k_project_box)
   int nPts = 0;
   float NormDen = 0, pixelSize = 0;
   int shiftX = 0, shiftY = 0;
@@ -648,17 +650,31 @@ int project_batch(bioem_hip_ctx *h, const BatchBuf &bb, hipStream_t st, int o0, 
 {
   const int N = h->N;
   HIP_CHECK(h, hipMemsetAsync(bb.tempDen, 0, sizeof(double) * nO, st));
+  // the pixels a point of the model can reach in any orientation, with its footprint: a box around the map centre
+  const double reach = h->modelRadius / (double) h->pixelSize;
+  const int boxLo = std::max(0, (int) std::floor(N / 2.0 + 0.5 - reach) - 1 - h->iradMax - std::max(0, std::max(h->shiftX, h->shiftY)));
+  const int boxHi = std::min(N - 1, (int) std::floor(N / 2.0 + 0.5 + reach) + 1 + h->iradMax - std::min(0, std::min(h->shiftX, h->shiftY)));
+  const int boxSide = boxHi - boxLo + 1;
+  if (h->dStamp && boxSide >= 1 && (size_t) boxSide * boxSide * sizeof(double) <= 52 * 1024 && N < 32768 &&
+      !getenv("BIOEM_PROJECT_BANDS") && !getenv("BIOEM_PROJECT_GLOBAL_ATOMICS"))
+  {
+    hipLaunchKernelGGL(k_project_box, dim3(std::min(nO, 3 * h->nCU)), dim3(256), sizeof(double) * boxSide * boxSide, st,
+                       h->dPts, h->nPts, h->dAngles, o0, h->isQuat, N, h->pixelSize, h->shiftX, h->shiftY, h->iradMax,
+                       h->dStamp, boxLo, boxSide, nO, bb.projReal, bb.tempDen);
+    HIP_CHECK(h, hipGetLastError());
+    return run_r2c(h, bb, st, bb.projReal, nullptr, nO);
+  }
   const int TR = 40960 / (8 * N); // rows of one LDS band: three blocks per CU
   // the record of every (orientation, point) borrows the row-pass buffer of the r2c that follows
   const bool coordsFit = (size_t) h->nPts * sizeof(ProjectRecord) <= (size_t) N * h->H * sizeof(double2);
-  if (TR >= 12 && h->iradMax <= 16 && N < 32768 && coordsFit && !getenv("BIOEM_PROJECT_GLOBAL_ATOMICS"))
+  if (TR >= 12 && h->iradMax <= 16 && h->dStamp && N < 32768 && coordsFit && !getenv("BIOEM_PROJECT_GLOBAL_ATOMICS"))
   {
     ProjectRecord *coords = reinterpret_cast<ProjectRecord *>(bb.rowSpec);
     hipLaunchKernelGGL(k_project_coords, dim3((h->nPts + 255) / 256, nO), dim3(256), 0, st, h->dPts, h->nPts, h->dAngles,
                        o0, h->isQuat, N, h->pixelSize, h->shiftX, h->shiftY, coords);
     const int units = ((N + TR - 1) / TR) * nO;
     hipLaunchKernelGGL(k_project_bands, dim3(std::min(units, 3 * h->nCU)), dim3(256), sizeof(double) * TR * N, st, coords,
-                       h->nPts, nO, N, TR, h->iradMax, h->pixelSize, bb.projReal, bb.tempDen);
+                       h->nPts, nO, N, TR, h->iradMax, h->dStamp, bb.projReal, bb.tempDen);
   }
   else
   {
@@ -1194,7 +1210,7 @@ int bioem_hip_destroy(bioem_hip_handle h)
                   h->dProjReal2, h->dTempDen2, h->dRowSpec2, h->dSpecRef2, h->dScratch2, h->dConv2, h->dParams2,
                   h->dTnyq, h->dTwNyq, h->dPartTiles, h->dConvShift, h->dDispLocal, h->dRankOfRow, h->dTileCenter, h->dTileValid,
                   h->dCand, h->dSend, h->dRecv, h->dMerged, h->dTwk2, h->dBtab, h->dPostC, h->dPostC2,
-                  h->dMapsReal, h->dConvReal, h->dDirectZ};
+                  h->dMapsReal, h->dConvReal, h->dDirectZ, h->dStamp};
   for (void *p : ptrs)
     if (p)
       hipFree(p);
@@ -1298,6 +1314,22 @@ int bioem_hip_upload_model(bioem_hip_handle h, const bioem_hip_model_point *pts,
   for (int n = 0; n < nPts; n++)
     if (pts[n].radius > pixelSize)
       h->iradMax = std::max(h->iradMax, (int) (pts[n].radius / pixelSize) + 1);
+  h->modelRadius = 0.;
+  for (int n = 0; n < nPts; n++)
+    h->modelRadius = std::max(h->modelRadius, std::sqrt((double) pts[n].pos[0] * pts[n].pos[0] + (double) pts[n].pos[1] * pts[n].pos[1] +
+                                                        (double) pts[n].pos[2] * pts[n].pos[2]));
+  if (h->dStamp)
+    hipFree(h->dStamp);
+  h->dStamp = nullptr;
+  if (h->iradMax <= 16 && nPts > 0)
+  {
+    const size_t cells = (size_t) nPts * (2 * h->iradMax + 1) * (2 * h->iradMax + 1);
+    HIP_CHECK(h, hipMalloc(&h->dStamp, sizeof(double) * cells));
+    hipLaunchKernelGGL(k_project_stamps, dim3((unsigned) ((cells + 255) / 256)), dim3(256), 0, h->stream, h->dPts, nPts,
+                       h->iradMax, pixelSize, h->dStamp);
+    HIP_CHECK(h, hipGetLastError());
+    HIP_CHECK(h, hipStreamSynchronize(h->stream));
+  }
   return 0;
 }
 

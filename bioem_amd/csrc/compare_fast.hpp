@@ -642,27 +642,41 @@ __global__ __launch_bounds__(256) void k_nyquist_rows(const CompareArgs a)
 #pragma unroll
   for (int d = 0; d < NW; d++)
     acc[d] = 0.f;
-  for (int rp = 0; rp < N1 * R2; rp++) // row pair = (k1, k2 pair): kx0 = N1*(2 k2p) + k1, kx1 = kx0 + N1
+  // row pair = (k1, k2 pair): kx0 = N1*(2 k2p) + k1, kx1 = kx0 + N1.  Eight pairs' operands are fetched at once: every
+  // load of a thread is a cache line of its own (one particle, one conv spectrum), and with one pair in flight the
+  // kernel was a chain of N/2 memory latencies (58 us for 30 720 comparisons at 128^2); the sums keep their order.
+  constexpr int NB = 8; // N/2 is a multiple of 64
+  for (int rp0 = 0; rp0 < N1 * R2; rp0 += NB)
   {
-    // the two k2 of a pair are adjacent in the comparison layout: one 16-byte load per operand
-    const size_t li = ((size_t) rp * H + N / 2) * 2;
-    const float4 c = *reinterpret_cast<const float4 *>(C + li);
-    const float4 f = *reinterpret_cast<const float4 *>(F + li);
-    // X = conv * conj(ref)   (bioem.cpp:1452-1455)
-    const float x0r = fmaf(c.x, f.x, c.y * f.y), x0i = fmaf(c.y, f.x, -(c.x * f.y));
-    const float x1r = fmaf(c.z, f.z, c.w * f.w), x1i = fmaf(c.w, f.z, -(c.z * f.w));
-    // twiddles of this row pair: block-uniform, contiguous -> a few wide scalar loads
-    const float4 *tw = reinterpret_cast<const float4 *>(a.twnyq + (size_t) rp * NW * 2);
+    float4 cb[NB], fb[NB];
 #pragma unroll
-    for (int d = 0; d < NW; d++)
+    for (int u = 0; u < NB; u++)
     {
-      const float4 w = tw[d]; // (w0.re, w0.im, w1.re, w1.im)
-      float v = acc[d];
-      v = fmaf(x0r, w.x, v);
-      v = fmaf(-x0i, w.y, v);
-      v = fmaf(x1r, w.z, v);
-      v = fmaf(-x1i, w.w, v);
-      acc[d] = v;
+      // the two k2 of a pair are adjacent in the comparison layout: one 16-byte load per operand
+      const size_t li = ((size_t) (rp0 + u) * H + N / 2) * 2;
+      cb[u] = *reinterpret_cast<const float4 *>(C + li);
+      fb[u] = *reinterpret_cast<const float4 *>(F + li);
+    }
+#pragma unroll
+    for (int u = 0; u < NB; u++)
+    {
+      const float4 c = cb[u], f = fb[u];
+      // X = conv * conj(ref)   (bioem.cpp:1452-1455)
+      const float x0r = fmaf(c.x, f.x, c.y * f.y), x0i = fmaf(c.y, f.x, -(c.x * f.y));
+      const float x1r = fmaf(c.z, f.z, c.w * f.w), x1i = fmaf(c.w, f.z, -(c.z * f.w));
+      // twiddles of this row pair: block-uniform, contiguous -> a few wide scalar loads
+      const float4 *tw = reinterpret_cast<const float4 *>(a.twnyq + (size_t) (rp0 + u) * NW * 2);
+#pragma unroll
+      for (int d = 0; d < NW; d++)
+      {
+        const float4 w = tw[d]; // (w0.re, w0.im, w1.re, w1.im)
+        float v = acc[d];
+        v = fmaf(x0r, w.x, v);
+        v = fmaf(-x0i, w.y, v);
+        v = fmaf(x1r, w.z, v);
+        v = fmaf(-x1i, w.w, v);
+        acc[d] = v;
+      }
     }
   }
   if (valid)

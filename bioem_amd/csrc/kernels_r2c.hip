@@ -65,6 +65,10 @@ hipError_t bioem_r2c_fft_launch(hipStream_t st, int nCU, const double *srcD, con
   const int perCU = std::max(1, std::min(4, (int) (160 * 1024 / (lds + 512))));
   const long rowItems = (long) nImg * ((N + 1) / 2), colItems = (long) nImg * a.H;
   const int rowUnits = (int) ((rowItems + a.G - 1) / a.G), colUnits = (int) ((colItems + a.G - 1) / a.G);
+  // three blocks per CU, i.e. at most 168 registers: beside a comparison kernel (three 168-register blocks per CU, the
+  // preparation stream at a lower priority) a block must fit the slot ONE retiring comparison block leaves, or the
+  // kernel waits for the whole comparison launch to drain (measured with a 191-register variant that fetched its
+  // inputs one unit ahead: faster alone, 3 % off the whole job at 1 000 particles)
   if (a.B <= 16)
   {
     hipLaunchKernelGGL((k_r2c_fft<true, 16, 3>), dim3(std::min(rowUnits, perCU * nCU)), dim3(kR2cThreads), lds, st, a);
@@ -72,8 +76,8 @@ hipError_t bioem_r2c_fft_launch(hipStream_t st, int nCU, const double *srcD, con
   }
   else
   {
-    hipLaunchKernelGGL((k_r2c_fft<true, 20, 2>), dim3(std::min(rowUnits, 2 * nCU)), dim3(kR2cThreads), lds, st, a);
-    hipLaunchKernelGGL((k_r2c_fft<false, 20, 2>), dim3(std::min(colUnits, 2 * nCU)), dim3(kR2cThreads), lds, st, a);
+    hipLaunchKernelGGL((k_r2c_fft<true, 20, 3>), dim3(std::min(rowUnits, perCU * nCU)), dim3(kR2cThreads), lds, st, a);
+    hipLaunchKernelGGL((k_r2c_fft<false, 20, 3>), dim3(std::min(colUnits, perCU * nCU)), dim3(kR2cThreads), lds, st, a);
   }
   return hipGetLastError();
 }

@@ -151,9 +151,12 @@ __global__ void k_project(const bioem_hip_model_point *__restrict__ pts, int nPt
 
 // The same projection in two steps, without global atomics or a zero-filled map (used while a band of >= 12 rows fits
 // 40 KiB of LDS, N <= 426):
+//   k_project_stamps  once per model: the weights of every sphere's footprint.  The reference evaluates them from the
+//                     integer pixel offsets to the sphere's centre pixel (bioem.cpp:1760-1790), so they do not depend
+//                     on the orientation: (2 iradMax + 1)^2 doubles per point, 0 outside the sphere;
 //   k_project_coords  rotates every model point once per orientation and leaves a 16-byte record: its pixel
 //                     (i << 16 | j, or -1 when the reference skips it: outside the map / sphere touching the border),
-//                     radius, density and the sphere's half width in pixels (0 for a point);
+//                     the point's index, density and the sphere's half width in pixels (0 for a point);
 //   k_project_bands   one block per band of TR map rows: lists the records that reach the band (512 points at a time,
 //                     2 048 loaded at once), splats them with one thread per (sphere, column of its
 //                     footprint) into LDS with double atomics and stores the band once.
@@ -161,9 +164,34 @@ __global__ void k_project(const bioem_hip_model_point *__restrict__ pts, int nPt
 struct alignas(16) ProjectRecord
 {
   int ij;
-  float radius, density;
+  int n;
+  float density;
   int irad;
 };
+
+// stamp[n][di + iradMax][dj + iradMax]: what the sphere of point n adds to the pixel (di, dj) away from its centre pixel
+__global__ void k_project_stamps(const bioem_hip_model_point *__restrict__ pts, int nPts, int iradMax, float pixelSize,
+                                 double *__restrict__ stamp)
+{
+  const int S = 2 * iradMax + 1;
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= nPts * S * S)
+    return;
+  const int n = e / (S * S), c = e - n * S * S;
+  const int di = c / S - iradMax, dj = c - (c / S) * S - iradMax;
+  const float radius = pts[n].radius, density = pts[n].density;
+  double w = 0.;
+  if (radius > pixelSize)
+  {
+    const int irad = (int) (radius / pixelSize) + 1;
+    const float rad2 = radius * radius;
+    // the reference's loop variables: ii - i = di, jj - j = dj
+    const float dist = ((float) (di) * (di) + (dj) * (dj)) * pixelSize * pixelSize;
+    if (di >= -irad && di <= irad && dj >= -irad && dj <= irad && dist < rad2)
+      w = (double) (pixelSize * pixelSize * 2 * sqrtf(rad2 - dist) * density * 3) / (4 * M_PI * radius * rad2);
+  }
+  stamp[e] = w;
+}
 
 __global__ void k_project_coords(const bioem_hip_model_point *__restrict__ pts, int nPts,
                                  const float4 *__restrict__ angles, int o0, int isQuat, int N, float pixelSize,
@@ -194,7 +222,7 @@ __global__ void k_project_coords(const bioem_hip_model_point *__restrict__ pts, 
   }
   ProjectRecord r;
   r.ij = ok ? (i << 16 | j) : -1;
-  r.radius = p.radius;
+  r.n = n;
   r.density = p.density;
   r.irad = irad;
   coords[(size_t) ob * nPts + n] = r;
@@ -203,8 +231,8 @@ __global__ void k_project_coords(const bioem_hip_model_point *__restrict__ pts, 
 constexpr int kProjectList = 512;
 
 __global__ __launch_bounds__(256) void k_project_bands(const ProjectRecord *__restrict__ coords, int nPts, int nO, int N,
-                                                        int TR, int iradMax, float pixelSize, double *__restrict__ proj,
-                                                        double *__restrict__ tempden)
+                                                        int TR, int iradMax, const double *__restrict__ stamp,
+                                                        double *__restrict__ proj, double *__restrict__ tempden)
 {
   extern __shared__ double band[]; // TR x N
   __shared__ ProjectRecord list[kProjectList];
@@ -256,27 +284,24 @@ __global__ __launch_bounds__(256) void k_project_bands(const ProjectRecord *__re
           const int en = it / S, dj = it - en * S - iradMax;
           const ProjectRecord q = list[en];
           const int i = q.ij >> 16, j = q.ij & 0xffff;
-          const float radius = q.radius, density = q.density;
           if (q.irad == 0)
           { // a point: bioem.cpp:1700-1712
             if (dj == 0)
             {
-              atomicAdd(&band[(i - r0) * N + j], (double) density);
-              td += (double) density;
+              atomicAdd(&band[(i - r0) * N + j], (double) q.density);
+              td += (double) q.density;
             }
             continue;
           }
           if (dj < -q.irad || dj > q.irad)
             continue;
-          const float rad2 = radius * radius;
           const int jj = j + dj;
+          const double *st = stamp + ((size_t) q.n * S + iradMax - i) * S + dj + iradMax; // row ii: st[ii * S]
           for (int ii = max(i - q.irad, r0); ii < min(i + q.irad + 1, r1); ii++)
           {
-            const float dist = ((float) (ii - i) * (ii - i) + (jj - j) * (jj - j)) * pixelSize * pixelSize;
-            if (dist < rad2)
+            const double w = st[ii * S];
+            if (w != 0.) // inside the sphere (dist < rad2: the weight is positive there)
             {
-              const double w = (double) (pixelSize * pixelSize * 2 * sqrtf(rad2 - dist) * density * 3) /
-                               (4 * M_PI * radius * rad2);
               atomicAdd(&band[(ii - r0) * N + jj], w);
               td += w;
             }
@@ -299,6 +324,119 @@ __global__ __launch_bounds__(256) void k_project_bands(const ProjectRecord *__re
     double *map = proj + (size_t) ob * N * N + (size_t) r0 * N;
     for (int e = threadIdx.x; e < (r1 - r0) * N; e += blockDim.x)
       map[e] = band[e];
+  }
+}
+
+// The projection of a model that stays inside a box of pixels around the map centre whatever the orientation
+// (box side = 2 (max |point| / pixelSize + widest footprint) + a margin, 52 KiB of doubles at most: 81 pixels): one block
+// per orientation keeps the box in LDS, every thread takes (point, footprint column) items straight from the model --
+// rotation, pixel, the reference's skip rules as in k_project_coords, the footprint from the stamps -- and the whole
+// map (zeros around the box) is stored once.  Against k_project_coords + k_project_bands there is no record list, no
+// band that scans all points to find its few, and no barrier between zeroing and storing; tempden is the block's own
+// sum.  A point that passes the reference's rules but falls outside the box (a quaternion that is not of unit length
+// stretches the model) is added to the stored map with global atomics in a second sweep.
+__global__ __launch_bounds__(256) void k_project_box(const bioem_hip_model_point *__restrict__ pts, int nPts,
+                                                      const float4 *__restrict__ angles, int o0, int isQuat, int N,
+                                                      float pixelSize, int shiftX, int shiftY, int iradMax,
+                                                      const double *__restrict__ stamp, int lo, int side, int nO,
+                                                      double *__restrict__ proj, double *__restrict__ tempden)
+{
+  extern __shared__ double box[]; // side x side
+  __shared__ double red[4];
+  __shared__ int outside;
+  const int S = 2 * iradMax + 1;
+  const int hi = lo + side - 1;
+  for (int ob = blockIdx.x; ob < nO; ob += gridDim.x)
+  {
+    __syncthreads(); // the previous map is stored
+    for (int e = threadIdx.x; e < side * side; e += blockDim.x)
+      box[e] = 0.;
+    if (threadIdx.x == 0)
+      outside = 0;
+    float rotmat[3][3];
+    rotation_matrix(angles[o0 + ob], isQuat, rotmat);
+    double *map = proj + (size_t) ob * N * N;
+    __syncthreads();
+    double td = 0.;
+    for (int sweep = 0; sweep < 2; sweep++)
+    {
+      // sweep 0: into the box; sweep 1 (only if a point fell outside it): those points into the stored map
+      for (int it = threadIdx.x; it < nPts * S; it += blockDim.x)
+      {
+        const int n = it / S, dj = it - n * S - iradMax;
+        const bioem_hip_model_point p = pts[n];
+        float rp[3] = {0.f, 0.f, 0.f};
+        for (int k = 0; k < 3; k++)
+          for (int j = 0; j < 3; j++)
+            rp[k] += rotmat[k][j] * p.pos[j];
+        int i = (int) floorf(rp[0] / pixelSize + (float) N / 2.0f + 0.5f);
+        int j = (int) floorf(rp[1] / pixelSize + (float) N / 2.0f + 0.5f);
+        bool ok;
+        int irad = 0;
+        if (p.radius <= pixelSize)
+          ok = !(i < 0 || j < 0 || i >= N || j >= N) && dj == 0;
+        else
+        {
+          i -= shiftX;
+          j -= shiftY;
+          irad = (int) (p.radius / pixelSize) + 1;
+          ok = !(i < irad || j < irad || i >= N - irad || j >= N - irad) && dj >= -irad && dj <= irad;
+        }
+        if (!ok)
+          continue;
+        const bool inbox = i - irad >= lo && i + irad <= hi && j - irad >= lo && j + irad <= hi;
+        if (inbox != (sweep == 0))
+        {
+          if (sweep == 0)
+            outside = 1;
+          continue;
+        }
+        double *dst = sweep == 0 ? box + (i - lo) * side + (j + dj - lo) : map + (size_t) i * N + j + dj;
+        const int ld = sweep == 0 ? side : N;
+        if (irad == 0)
+        { // a point: bioem.cpp:1700-1712
+          atomicAdd(dst, (double) p.density);
+          td += (double) p.density;
+          continue;
+        }
+        // footprint column dj of the sphere: rows i - irad .. i + irad, five stamp entries in flight
+        const double *st = stamp + ((size_t) n * S + iradMax) * S + dj + iradMax;
+        for (int d0 = -irad; d0 <= irad; d0 += 5)
+        {
+          double w[5];
+#pragma unroll
+          for (int u = 0; u < 5; u++)
+            w[u] = d0 + u <= irad ? st[(d0 + u) * S] : 0.;
+#pragma unroll
+          for (int u = 0; u < 5; u++)
+            if (w[u] != 0.) // inside the sphere (dist < rad2: the weight is positive there)
+            {
+              atomicAdd(dst + (d0 + u) * ld, w[u]);
+              td += w[u];
+            }
+        }
+      }
+      __syncthreads(); // every splat of this sweep is done
+      if (sweep == 0)
+      {
+        for (int e = threadIdx.x; e < N * N; e += blockDim.x)
+        {
+          const int r = e / N, c = e - r * N;
+          map[e] = (r >= lo && r <= hi && c >= lo && c <= hi) ? box[(r - lo) * side + c - lo] : 0.;
+        }
+        if (!outside)
+          break;
+        __threadfence();
+        __syncthreads();
+      }
+    }
+    for (int o = 32; o > 0; o >>= 1)
+      td += __shfl_down(td, o);
+    if ((threadIdx.x & 63) == 0)
+      red[threadIdx.x >> 6] = td;
+    __syncthreads();
+    if (threadIdx.x == 0)
+      tempden[ob] = (red[0] + red[1]) + (red[2] + red[3]);
   }
 }
 

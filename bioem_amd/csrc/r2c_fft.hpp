@@ -256,60 +256,51 @@ struct R2cArgs
   int plane;             // doubles per LDS plane, max(G * YG, N * Gp)
 };
 
-// stage 1 of transform `item` (block-local g), sub-sequence j1
+// stage 1 of transform `item` (block-local g), sub-sequence j1.  (A group's transforms beyond the last item take the
+// last item again: their results are never stored.)
 template <int B, bool ROWS>
 __device__ __forceinline__ void r2c_stage1(const R2cArgs &a, const double2 *tw, double *Yr, double *Yi, int g, int j1,
                                            long item, long nItems)
 {
   double re[B], im[B];
   const int N = a.N, A = a.A;
-  if (item < nItems)
+  item = item < nItems ? item : nItems - 1;
+  if constexpr (ROWS)
   {
-    if constexpr (ROWS)
+    const int NP = (N + 1) >> 1;
+    const int b = (int) (item / NP), i = 2 * (int) (item - (long) b * NP);
+    const int second = i + 1 < N ? N : 0; // odd N: the last row is paired with itself, the copy is dropped on the way out
+    const size_t r0 = ((size_t) b * N + i) * N + j1;
+    if (a.srcD)
     {
-      const int NP = (N + 1) >> 1;
-      const int b = (int) (item / NP), i = 2 * (int) (item - (long) b * NP);
-      const bool two = i + 1 < N;
-      const size_t r0 = ((size_t) b * N + i) * N + j1;
-      if (a.srcD)
-      {
-        const float ratio = a.NormDen / (float) a.tempden[b]; // bioem.cpp:1808-1818
+      const float ratio = a.NormDen / (float) a.tempden[b]; // bioem.cpp:1808-1818
 #pragma unroll
-        for (int j2 = 0; j2 < B; j2++)
-        {
-          const float v0 = (float) a.srcD[r0 + A * j2] * ratio;
-          const float v1 = two ? (float) a.srcD[r0 + N + A * j2] * ratio : 0.f;
-          re[j2] = (double) v0;
-          im[j2] = (double) v1;
-        }
-      }
-      else
+      for (int j2 = 0; j2 < B; j2++)
       {
-#pragma unroll
-        for (int j2 = 0; j2 < B; j2++)
-        {
-          re[j2] = (double) a.srcF[r0 + A * j2];
-          im[j2] = two ? (double) a.srcF[r0 + N + A * j2] : 0.;
-        }
+        re[j2] = (double) ((float) a.srcD[r0 + A * j2] * ratio);
+        im[j2] = (double) ((float) a.srcD[r0 + second + A * j2] * ratio);
       }
     }
     else
     {
-      const size_t r0 = (size_t) item * N + j1; // item = b * H + k
 #pragma unroll
       for (int j2 = 0; j2 < B; j2++)
       {
-        const double2 v = a.specIn[r0 + A * j2];
-        re[j2] = v.x;
-        im[j2] = v.y;
+        re[j2] = (double) a.srcF[r0 + A * j2];
+        im[j2] = (double) a.srcF[r0 + second + A * j2];
       }
     }
   }
   else
   {
+    const size_t r0 = (size_t) item * N + j1; // item = b * H + k
 #pragma unroll
     for (int j2 = 0; j2 < B; j2++)
-      re[j2] = im[j2] = 0.;
+    {
+      const double2 v = a.specIn[r0 + A * j2];
+      re[j2] = v.x;
+      im[j2] = v.y;
+    }
   }
   r2c_fft_fwd<B>(re, im);
   double *yr = Yr + g * a.YG + j1 * (B + 1), *yi = Yi + g * a.YG + j1 * (B + 1);
@@ -354,6 +345,9 @@ __device__ __forceinline__ void r2c_stage2(const R2cArgs &a, double *Pr, double 
 
 #define R2C_LENGTHS(X) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15) X(16) X(17) X(18) X(19) X(20)
 
+// (Tried: the stage-1 inputs of the next unit fetched while this one goes through stage 2 and the stores -- 64 more
+// registers.  Alone, 384 images of 224^2: rows 81 -> 65 us, columns 61 -> 71 us; beside a comparison kernel the 191
+// registers do not fit the slot a retiring comparison block leaves, see kernels_r2c.hip.)
 template <bool ROWS, int LMAX, int NBLK>
 __global__ __launch_bounds__(kR2cThreads, NBLK) void k_r2c_fft(const R2cArgs a)
 {
@@ -384,7 +378,7 @@ __global__ __launch_bounds__(kR2cThreads, NBLK) void k_r2c_fft(const R2cArgs a)
 #define X(L)                                                                                                            \
   case L:                                                                                                               \
     if constexpr (L <= LMAX)                                                                                            \
-      r2c_stage1<L, ROWS>(a, tw, Pr, Pi, g1, j1, item0 + g1, nItems);                                                   \
+      r2c_stage1<L, ROWS>(a, tw, Pr, Pi, g1, j1, item0 + g1, nItems);                                                                 \
     break;
         R2C_LENGTHS(X)
 #undef X
