@@ -594,6 +594,17 @@ hipError_t dft_allow_lds(int N)
                              (int) dft_cols_lds(N));
 }
 
+// k_convolve_sums keeps two tiles of terms for six CTFs per orientation in dynamic LDS: 45 KiB per orientation of a block
+hipError_t conv_allow_lds()
+{
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_convolve_sums<2>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int) conv_lds_bytes<2>());
+  if (e != hipSuccess)
+    return e;
+  return hipFuncSetAttribute(reinterpret_cast<const void *>(k_convolve_sums<3>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                             (int) conv_lds_bytes<3>());
+}
+
 // r2c of nImg images (double projection maps scaled by NormDen / tempden, or float maps) into `out` (reference layout);
 // rowSpec holds the row pass (N x H double2 per image).  dft_allow_lds(N) must have run on this device.
 hipError_t launch_r2c(hipStream_t st, int nCU, const double *srcD, const float *srcF, const double *tempDen, float NormDen,
@@ -790,8 +801,18 @@ int convolve_batch(bioem_hip_ctx *h, const BatchBuf &bb, hipStream_t st, int nO,
   const char *fe = getenv("BIOEM_CONVOLVE_FUSED");
   if (fe ? atoi(fe) != 0 : h->nMaps <= 64)
   {
-    hipLaunchKernelGGL(k_convolve_sums, dim3((nC + kConvCtfs - 1) / kConvCtfs, nO), dim3(kConvThreads), 0, st, bb.specRef, h->dCTF,
-                       h->dCtfParam, h->N, h->H, h->fast, h->N1, c0, nC, bb.conv, bb.params);
+    const char *je = getenv("BIOEM_CONVOLVE_J"); // orientations per block (1, 2, 3): timing experiments
+    const int J = je ? atoi(je) : 2;
+    const int nCg = (nC + kConvCtfs - 1) / kConvCtfs;
+    if (J == 1)
+      hipLaunchKernelGGL(k_convolve_sums<1>, dim3(nCg, nO), dim3(kConvThreads), conv_lds_bytes<1>(), st, bb.specRef, h->dCTF,
+                         h->dCtfParam, h->N, h->H, h->fast, h->N1, c0, nC, nO, bb.conv, bb.params);
+    else if (J == 3)
+      hipLaunchKernelGGL(k_convolve_sums<3>, dim3(nCg, (nO + 2) / 3), dim3(kConvThreads), conv_lds_bytes<3>(), st, bb.specRef,
+                         h->dCTF, h->dCtfParam, h->N, h->H, h->fast, h->N1, c0, nC, nO, bb.conv, bb.params);
+    else
+      hipLaunchKernelGGL(k_convolve_sums<2>, dim3(nCg, (nO + 1) / 2), dim3(kConvThreads), conv_lds_bytes<2>(), st, bb.specRef,
+                         h->dCTF, h->dCtfParam, h->N, h->H, h->fast, h->N1, c0, nC, nO, bb.conv, bb.params);
     HIP_CHECK(h, hipGetLastError());
     return 0;
   }
@@ -870,6 +891,7 @@ static int create_impl(bioem_hip_handle *out, int device, const bioem_hip_param_
   HIP_CHECK(h, hipSetDevice(device));
   HIP_CHECK(h, hipDeviceGetAttribute(&h->nCU, hipDeviceAttributeMultiprocessorCount, device));
   HIP_CHECK(h, dft_allow_lds(N));
+  HIP_CHECK(h, conv_allow_lds());
   if (getenv("BIOEM_PREP_OCCUPANCY"))
   { // blocks per CU the runtime grants the preparation kernels at this image size
     int nb = 0;

@@ -760,9 +760,24 @@ __global__ __launch_bounds__(64) void k_parseval_ordered(const float *__restrict
 // it is written when the first of them comes by (its partner's product is formed there for the store, and once more
 // when its own position in the order is reached: same operands, same bits).
 // ------------------------------------------------------------------------------------------------
-constexpr int kConvTile = 1024;
 constexpr int kConvCtfs = 6;
+constexpr int kConvThreads = 1024; // one adding wave, fifteen producing waves
+// a tile is one position per producing thread: its loads (the projection element, its partner row, the CTFs' values)
+// go out together and a tile costs the producers one round trip to memory.  (Round 3 had tiles of 1 024: a second,
+// nearly empty round trip for 64 of them -- 256 orientations x 5 CTFs at 224^2: 233 -> 132 us.  Two or three positions
+// per thread change nothing: the adding wave is the longer side.)
+constexpr int kConvTile = kConvThreads - 64;
 constexpr int kConvStride = kConvTile + 4; // chain stride in LDS (floats): the adding lanes read different banks
+// J orientations per block: the adding wave carries their chains side by side (independent additions between the
+// dependent ones), the producers read the CTFs once for all of them.  Measured alone, 5 CTFs at 224^2, block time
+// 130 / 200 / 265 us for J = 1 / 2 / 3 whatever the number of blocks up to one per CU; two J = 1 blocks on a CU take
+// twice as long as one.  Timing-only builds priced the parts of a J = 1 block on an otherwise idle chip: no stores
+// 130 -> 127 us, no CTF loads 130 -> 134, no additions 130 -> 73 (with every CU busy 139 -> 126: the producers then
+// take as long as the chain); 32, 64 or 128 terms in flight from LDS, or the adding wave alone on its SIMD, change
+// nothing.  Whole jobs of 10...20 particles: J = 2 is 3 % ahead of J = 1; J = 3 wins where it saves a round of blocks
+// (768 orientations x 5 CTFs: +4 %) and loses elsewhere (-4 %): J = 2 it is (BIOEM_CONVOLVE_J overrides).
+template <int J>
+constexpr size_t conv_lds_bytes() { return sizeof(float) * 2 * J * kConvCtfs * kConvStride; }
 
 // block barrier that orders LDS traffic only: __syncthreads() would also wait for the spectra on their way to memory
 __device__ inline void lds_barrier()
@@ -770,74 +785,92 @@ __device__ inline void lds_barrier()
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
-constexpr int kConvThreads = 1024; // one adding wave, fifteen producing waves: a tile costs them one round of loads
-
+template <int J>
 __global__ __launch_bounds__(kConvThreads) void
 k_convolve_sums(const float2 *__restrict__ proj, const float2 *__restrict__ ctf, const float *__restrict__ ctfParam,
-                int N, int H, int fast, int N1, int c0, int nC, float2 *__restrict__ conv, bioem_hip_param5 *__restrict__ params)
+                int N, int H, int fast, int N1, int c0, int nC, int nO, float2 *__restrict__ conv,
+                bioem_hip_param5 *__restrict__ params)
 {
-  __shared__ __align__(16) float terms[2][kConvCtfs][kConvStride];
-  __shared__ float sC[kConvCtfs];
-  const int ob = blockIdx.y, cg = blockIdx.x * kConvCtfs;
+  extern __shared__ __align__(16) float terms[]; // [2][J][kConvCtfs][kConvStride]
+  __shared__ float sC[J][kConvCtfs];
+  const int ob0 = blockIdx.y * J, cg = blockIdx.x * kConvCtfs;
+  const int nJ = min(J, nO - ob0);
   const int nCb = min(kConvCtfs, nC - cg);
   const int M = N * H;
   const int even = ((N & 1) == 0);
   const int jend = even ? H - 1 : H;
-  const float2 *P = proj + (size_t) ob * M;
   const float2 *K0 = ctf + (size_t) (c0 + cg) * M;
-  float2 *O0 = conv + ((size_t) ob * nC + cg) * M;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int nt = (M + kConvTile - 1) / kConvTile;
   auto produce = [&](int t) {
-    float(*T)[kConvStride] = terms[t & 1];
-    for (int e = (int) threadIdx.x - 64; e < kConvTile; e += kConvThreads - 64)
+    float *T = terms + (size_t) (t & 1) * J * kConvCtfs * kConvStride;
+    const int e = (int) threadIdx.x - 64;
+    const int pos0 = t * kConvTile + e;
+    const bool valid = pos0 < M; // beyond the spectrum: the last element is read, a zero term left, nothing stored
+    const int pos = valid ? pos0 : M - 1;
+    const int i = pos / H, r = pos - i * H;
+    const int j = r < jend - 1 ? r + 1 : (r == jend - 1 ? 0 : H - 1);
+    const bool twice = j >= 1 && j < jend;
+    const size_t ij = (size_t) i * H + j;
+    bool first = false;
+    size_t word = 0, partner = ij;
+    if (fast)
     {
-      const int pos = t * kConvTile + e;
-      if (pos >= M)
-      { // beyond the spectrum: x + 0 = x
-        for (int c = 0; c < nCb; c++)
-          T[c][e] = 0.f;
-        continue;
-      }
-      const int i = pos / H, r = pos - i * H;
-      const int j = r < jend - 1 ? r + 1 : (r == jend - 1 ? 0 : H - 1);
-      const bool twice = j >= 1 && j < jend;
-      const size_t ij = (size_t) i * H + j;
-      const float2 p = P[ij];
-      bool first = false;
-      float2 p1 = make_float2(0.f, 0.f);
-      size_t word = 0;
-      if (fast)
+      const int k2 = i / N1, k1i = i - k2 * N1;
+      first = !(k2 & 1);
+      word = (size_t) (k1i * fast + (k2 >> 1)) * H + j;
+      partner = first ? ij + (size_t) N1 * H : ij;
+    }
+    // every load of the tile first ...
+    float2 p[J], p1[J], kv[kConvCtfs], k1[kConvCtfs];
+#pragma unroll
+    for (int o = 0; o < J; o++)
+    {
+      const float2 *P = proj + (size_t) (ob0 + min(o, nJ - 1)) * M;
+      p[o] = P[ij];
+      p1[o] = P[partner];
+    }
+#pragma unroll
+    for (int c = 0; c < kConvCtfs; c++)
+      if (c < nCb)
       {
-        const int k2 = i / N1, k1 = i - k2 * N1;
-        first = !(k2 & 1);
-        word = (size_t) (k1 * fast + (k2 >> 1)) * H + j;
-        if (first)
-          p1 = P[ij + (size_t) N1 * H];
+        const float2 *Kc = K0 + (size_t) c * M;
+        kv[c] = Kc[ij];
+        k1[c] = Kc[partner];
       }
-      for (int c = 0; c < nCb; c++)
-      {
-        const float2 *K = K0 + (size_t) c * M;
-        float2 *O = O0 + (size_t) c * M;
-        const float2 k = K[ij];
-        float2 o;
-        o.x = (p.x * k.x + p.y * k.y);
-        o.y = (p.y * k.x - p.x * k.y);
-        const float tt = o.x * o.x + o.y * o.y;
-        T[c][e] = twice ? tt * 2 : tt;
-        if (!fast)
-          O[ij] = o;
-        else if (first)
+    // ... then the products, the terms and the stores
+#pragma unroll
+    for (int o = 0; o < J; o++)
+    {
+      if (o >= nJ)
+        break;
+      float2 *O0 = conv + ((size_t) (ob0 + o) * nC + cg) * M;
+#pragma unroll
+      for (int c = 0; c < kConvCtfs; c++)
+        if (c < nCb)
         {
-          const float2 k1v = K[ij + (size_t) N1 * H];
-          float2 o1;
-          o1.x = (p1.x * k1v.x + p1.y * k1v.y);
-          o1.y = (p1.y * k1v.x - p1.x * k1v.y);
-          reinterpret_cast<float4 *>(O)[word] = make_float4(o.x, o.y, o1.x, o1.y);
+          float2 *O = O0 + (size_t) c * M;
+          const float2 k = kv[c];
+          float2 v;
+          v.x = (p[o].x * k.x + p[o].y * k.y);
+          v.y = (p[o].y * k.x - p[o].x * k.y);
+          const float tt = v.x * v.x + v.y * v.y;
+          T[(o * kConvCtfs + c) * kConvStride + e] = valid ? (twice ? tt * 2 : tt) : 0.f; // x + 0 = x
+          if (!valid)
+            continue;
+          if (!fast)
+            O[ij] = v;
+          else if (first)
+          {
+            const float2 k1v = k1[c];
+            float2 v1;
+            v1.x = (p1[o].x * k1v.x + p1[o].y * k1v.y);
+            v1.y = (p1[o].y * k1v.x - p1[o].x * k1v.y);
+            reinterpret_cast<float4 *>(O)[word] = make_float4(v.x, v.y, v1.x, v1.y);
+          }
+          if (i == 0 && j == 0)
+            sC[o][c] = v.x;
         }
-        if (i == 0 && j == 0)
-          sC[c] = o.x;
-      }
     }
   };
   if (wave != 0)
@@ -845,22 +878,38 @@ k_convolve_sums(const float2 *__restrict__ proj, const float2 *__restrict__ ctf,
   else
     __builtin_amdgcn_s_setprio(3); // the adding wave is the critical path: it issues ahead of the producers of its SIMD
   lds_barrier();
-  float ss = 0.f;
+  float ss[J];
+#pragma unroll
+  for (int o = 0; o < J; o++)
+    ss[o] = 0.f;
   for (int t = 0; t < nt; t++)
   {
     if (wave == 0)
     {
       if (lane < nCb)
       {
-        const float4 *q = reinterpret_cast<const float4 *>(&terms[t & 1][lane][0]);
-#pragma unroll 8
-        for (int k = 0; k < kConvTile / 4; k++)
+        const float *T = terms + (size_t) (t & 1) * J * kConvCtfs * kConvStride;
+        const int n4 = (min(kConvTile, M - t * kConvTile) + 3) >> 2; // the last tile ends with the spectrum
+#pragma unroll 4
+        for (int k = 0; k < n4; k++)
         {
-          const float4 v = q[k];
-          ss += v.x;
-          ss += v.y;
-          ss += v.z;
-          ss += v.w;
+          float4 v[J];
+#pragma unroll
+          for (int o = 0; o < J; o++)
+            v[o] = reinterpret_cast<const float4 *>(T + (size_t) (o * kConvCtfs + lane) * kConvStride)[k];
+          // one term after the other as the reference does (bioem.cpp:1896-1914), the J chains interleaved
+#pragma unroll
+          for (int o = 0; o < J; o++)
+            ss[o] += v[o].x;
+#pragma unroll
+          for (int o = 0; o < J; o++)
+            ss[o] += v[o].y;
+#pragma unroll
+          for (int o = 0; o < J; o++)
+            ss[o] += v[o].z;
+#pragma unroll
+          for (int o = 0; o < J; o++)
+            ss[o] += v[o].w;
         }
       }
     }
@@ -871,13 +920,18 @@ k_convolve_sums(const float2 *__restrict__ proj, const float2 *__restrict__ ctf,
   if (wave == 0 && lane < nCb)
   {
     const int c = c0 + cg + lane;
-    bioem_hip_param5 r;
-    r.amp = ctfParam[3 * c + 0];
-    r.pha = ctfParam[3 * c + 1];
-    r.env = ctfParam[3 * c + 2];
-    r.sumC = sC[lane];
-    r.sumsquareC = ss / (float) (N * N);
-    params[(size_t) ob * nC + cg + lane] = r;
+#pragma unroll
+    for (int o = 0; o < J; o++)
+      if (o < nJ)
+      {
+        bioem_hip_param5 r;
+        r.amp = ctfParam[3 * c + 0];
+        r.pha = ctfParam[3 * c + 1];
+        r.env = ctfParam[3 * c + 2];
+        r.sumC = sC[o][lane];
+        r.sumsquareC = ss[o] / (float) (N * N);
+        params[(size_t) (ob0 + o) * nC + cg + lane] = r;
+      }
   }
 }
 
