@@ -342,6 +342,31 @@ BatchBuf batch_buf(bioem_hip_ctx *h, int which)
 
 // ids == nullptr: row oc of the launch is (orient0 + oc / convPerOrient, conv0 + oc % convPerOrient) (native path);
 // otherwise ids[oc] = {orientation, CTF} and segs[0..nSeg) = runs of equal orientation (compat ring)
+// the Nyquist column of the 64-column blocks (N / 2 a multiple of 64): its window rows by direct summation.  With 64
+// particles or fewer four threads share a (particle, spectrum) pair (a block per 4 x 16 pairs), else one (16 x 16).
+template <int Q>
+void launch_nyquist_rows(bioem_hip_ctx *h, const CompareArgs &aw, int WD, int nOC)
+{
+  const int PB = 16 / Q;
+  const dim3 gridq((unsigned) (((size_t) (h->nMaps + PB - 1) / PB) * ((nOC + 15) / 16)));
+  switch (WD)
+  {
+#define X(W)                                                                                                            \
+  case W:                                                                                                               \
+    hipLaunchKernelGGL((k_nyquist_rows<W, Q>), gridq, dim3(256), 0, h->stream, aw);                                     \
+    break;
+    X(5) X(10) X(13) X(15) X(20) X(31) X(42)
+#undef X
+  }
+}
+void launch_nyquist(bioem_hip_ctx *h, const CompareArgs &aw, int WD, int nOC)
+{
+  if (h->nMaps <= 64)
+    launch_nyquist_rows<4>(h, aw, WD, nOC);
+  else
+    launch_nyquist_rows<1>(h, aw, WD, nOC);
+}
+
 int launch_compare_fold(bioem_hip_ctx *h, const BatchBuf &bb, int nOC, int orient0, int conv0, int convPerOrient,
                         const int2 *ids = nullptr, const int4 *segs = nullptr, int nSeg = 0)
 {
@@ -415,15 +440,7 @@ int launch_compare_fold(bioem_hip_ctx *h, const BatchBuf &bb, int nOC, int orien
     aw.ts = h->w2TS;
     aw.nyqWD = h->nyqWD;
     if (h->nyq)
-    {
-      const dim3 gridq((unsigned) (((size_t) (h->nMaps + 15) / 16) * ((nOC + 15) / 16)));
-      if (h->nyqWD == 20)
-        hipLaunchKernelGGL(k_nyquist_rows<20>, gridq, dim3(256), 0, h->stream, aw);
-      else if (h->nyqWD == 31)
-        hipLaunchKernelGGL(k_nyquist_rows<31>, gridq, dim3(256), 0, h->stream, aw);
-      else
-        hipLaunchKernelGGL(k_nyquist_rows<42>, gridq, dim3(256), 0, h->stream, aw);
-    }
+      launch_nyquist(h, aw, h->nyqWD == 20 || h->nyqWD == 31 ? h->nyqWD : 42, nOC);
     hipLaunchKernelGGL(reinterpret_cast<fast_kernel_t>(const_cast<void *>(h->fn)), dim3((unsigned) ((size_t) nOC * h->nMaps)), dim3(64 * h->w2NW), h->ldsBytes, h->stream, aw);
   }
   else if (h->fastm2)
@@ -432,30 +449,14 @@ int launch_compare_fold(bioem_hip_ctx *h, const BatchBuf &bb, int nOC, int orien
     aw.twk = h->dTwk2;
     aw.nyqWD = h->nyqWD;
     if (h->nyq)
-    {
-      const dim3 gridq((unsigned) (((size_t) (h->nMaps + 15) / 16) * ((nOC + 15) / 16)));
-      if (h->nyqWD == 20)
-        hipLaunchKernelGGL(k_nyquist_rows<20>, gridq, dim3(256), 0, h->stream, aw);
-      else
-        hipLaunchKernelGGL(k_nyquist_rows<31>, gridq, dim3(256), 0, h->stream, aw);
-    }
+      launch_nyquist(h, aw, h->nyqWD == 20 ? 20 : 31, nOC);
     hipLaunchKernelGGL(reinterpret_cast<fast_kernel_t>(const_cast<void *>(h->fn)), grid, dim3(256), h->ldsBytes, h->stream, aw);
   }
   else if (h->fast || h->rowsK)
   {
     auto launch_window = [&](const CompareArgs &aw) {
       if (h->nyq)
-      { // Nyquist column of the 64-column blocks (N / 2 a multiple of 64): its window rows by direct summation
-        const dim3 gridq((unsigned) (((size_t) (h->nMaps + 15) / 16) * ((nOC + 15) / 16)));
-        if (h->winD == 5)
-          hipLaunchKernelGGL(k_nyquist_rows<5>, gridq, dim3(256), 0, h->stream, aw);
-        else if (h->winD == 10)
-          hipLaunchKernelGGL(k_nyquist_rows<10>, gridq, dim3(256), 0, h->stream, aw);
-        else if (h->winD == 13)
-          hipLaunchKernelGGL(k_nyquist_rows<13>, gridq, dim3(256), 0, h->stream, aw);
-        else
-          hipLaunchKernelGGL(k_nyquist_rows<15>, gridq, dim3(256), 0, h->stream, aw);
-      }
+        launch_nyquist(h, aw, h->winD == 5 || h->winD == 10 || h->winD == 13 ? h->winD : 15, nOC);
       hipLaunchKernelGGL(reinterpret_cast<fast_kernel_t>(const_cast<void *>(h->fn)), grid, dim3(256), h->ldsBytes, h->stream, aw);
     };
     if (!h->tileT)
@@ -519,9 +520,13 @@ int launch_compare_fold(bioem_hip_ctx *h, const BatchBuf &bb, int nOC, int orien
       hipLaunchKernelGGL(k_fold_angles, dim3((unsigned) ((nt + 255) / 256)), dim3(256), 0, h->stream, h->dPartials,
                          h->maxOC, nOC, h->nMaps, orient0, convPerOrient, segs, nRuns, pang, h->angO0);
     }
-    hipLaunchKernelGGL(k_fold_wave, dim3((h->nMaps + 3) / 4), dim3(256), 0, h->stream, h->dPartials, h->maxOC, nOC,
-                       h->nMaps, bb.params, h->dSumRef, h->dDisp, h->nd, h->pd, orient0, conv0, convPerOrient, ids,
-                       pmap);
+    if (h->nMaps <= 64 && nOC >= 1024)
+      hipLaunchKernelGGL(k_fold_wave<4>, dim3(h->nMaps), dim3(256), 0, h->stream, h->dPartials, h->maxOC, nOC, h->nMaps,
+                         bb.params, h->dSumRef, h->dDisp, h->nd, h->pd, orient0, conv0, convPerOrient, ids, pmap);
+    else
+      hipLaunchKernelGGL(k_fold_wave<1>, dim3((h->nMaps + 3) / 4), dim3(256), 0, h->stream, h->dPartials, h->maxOC, nOC,
+                         h->nMaps, bb.params, h->dSumRef, h->dDisp, h->nd, h->pd, orient0, conv0, convPerOrient, ids,
+                         pmap);
   }
   HIP_CHECK(h, hipGetLastError());
   if (phase_end(h, h->stream)) // comparison = the kernels of the launch and the fold behind them (what compareRefMaps does)

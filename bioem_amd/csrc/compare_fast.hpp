@@ -625,15 +625,22 @@ __global__ __launch_bounds__(256, BIOEM_FAST_WAVES_PER_SIMD) void k_compare_fast
 //   tnyq[p][oc][m + WD] = Re sum_kx conv[oc][kx][N/2] * conj(ref[p][kx][N/2]) * w_N^(kx m gs),  m = -WD..WD
 // The twiddles are uniform over the block and tabulated per row pair (twnyq): wide scalar loads.
 // ------------------------------------------------------------------------------------------------
-template <int WD>
+// Q = 4 (few particles: 16 x 16 pairs per block are 192 blocks for 10 particles x 3 072 spectra, every thread a chain of
+// N/2 row pairs): the four waves of a block share its 4 x 16 pairs, wave w the w-th quarter of the row pairs in order
+// (the twiddles stay wave-uniform), the quarters added through LDS as (q0 + q1) + (q2 + q3).
+template <int WD, int Q>
 __global__ __launch_bounds__(256) void k_nyquist_rows(const CompareArgs a)
 {
+  static_assert(Q == 1 || Q == 4, "one thread per pair, or one per pair and wave");
   constexpr int NW = 2 * WD + 1;
+  __shared__ float part[Q == 4 ? 2 * 64 * NW : 1];
   const int N = a.N, H = a.H, N1 = a.N1;
   const int R2 = N / (2 * N1);
   const int tilesOC = (a.nOC + 15) / 16;
   const int tp = blockIdx.x / tilesOC, to = blockIdx.x - tp * tilesOC;
-  const int p = tp * 16 + (threadIdx.x >> 4), oc = to * 16 + (threadIdx.x & 15);
+  const int q = Q == 1 ? 0 : __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6));
+  const int t = Q == 1 ? threadIdx.x : threadIdx.x & 63;
+  const int p = tp * (16 / Q) + (t >> 4), oc = to * 16 + (t & 15);
   const bool valid = p < a.nMaps && oc < a.nOC;
   const size_t M = (size_t) N * H;
   const float2 *F = a.ref + (size_t) (valid ? p : 0) * M;
@@ -642,11 +649,12 @@ __global__ __launch_bounds__(256) void k_nyquist_rows(const CompareArgs a)
 #pragma unroll
   for (int d = 0; d < NW; d++)
     acc[d] = 0.f;
+  const int nRP = N1 * R2 / Q; // row pairs of this thread: [q nRP, (q + 1) nRP)
   // row pair = (k1, k2 pair): kx0 = N1*(2 k2p) + k1, kx1 = kx0 + N1.  Eight pairs' operands are fetched at once: every
   // load of a thread is a cache line of its own (one particle, one conv spectrum), and with one pair in flight the
   // kernel was a chain of N/2 memory latencies (58 us for 30 720 comparisons at 128^2); the sums keep their order.
-  constexpr int NB = 8; // N/2 is a multiple of 64
-  for (int rp0 = 0; rp0 < N1 * R2; rp0 += NB)
+  constexpr int NB = WD > 31 ? 4 : 8; // N/2 is a multiple of 64, a quarter of it of 16
+  for (int rp0 = q * nRP; rp0 < (q + 1) * nRP; rp0 += NB)
   {
     float4 cb[NB], fb[NB];
 #pragma unroll
@@ -679,7 +687,39 @@ __global__ __launch_bounds__(256) void k_nyquist_rows(const CompareArgs a)
       }
     }
   }
-  if (valid)
+  if (Q == 4)
+  {
+    // (q0 + q1) in wave 0, (q2 + q3) in wave 2, then their sum in wave 0
+    float *mine = part + ((q >> 1) * 64 + t) * NW;
+    if (q & 1)
+    {
+#pragma unroll
+      for (int d = 0; d < NW; d++)
+        mine[d] = acc[d];
+    }
+    __syncthreads();
+    if (!(q & 1))
+    {
+#pragma unroll
+      for (int d = 0; d < NW; d++)
+        acc[d] += mine[d];
+    }
+    __syncthreads();
+    if (q == 2)
+    {
+#pragma unroll
+      for (int d = 0; d < NW; d++)
+        mine[d] = acc[d];
+    }
+    __syncthreads();
+    if (q == 0)
+    {
+#pragma unroll
+      for (int d = 0; d < NW; d++)
+        acc[d] += part[(64 + t) * NW + d];
+    }
+  }
+  if (valid && q == 0)
   {
     float *o = a.tnyq + ((size_t) p * a.ldPart + oc) * NW;
 #pragma unroll

@@ -104,6 +104,10 @@ __global__ void k_fold_angles(const Partial *__restrict__ partials, int ldPart, 
 // the FIRST maximum (lowest index), then combined with the running state exactly like the sequential fold.
 // The log-sum-exp merge is associative, so the result equals k_fold's up to double rounding (1e-16).
 // ------------------------------------------------------------------------------------------------
+// WPP = 4 (few particles: one wave per particle left the chip to ten waves walking 48 partials each, 40 us per launch):
+// the four waves of a block share one particle, wave w the w-th quarter of its partials; their results are merged in
+// wave order through LDS by the same first-maximum rule.
+template <int WPP>
 __global__ __launch_bounds__(256) void k_fold_wave(const Partial *__restrict__ partials, int ldPart, int nOC,
                                                    int nMaps, const bioem_hip_param5 *__restrict__ params,
                                                    const float *__restrict__ sumRef, const int *__restrict__ disp,
@@ -111,15 +115,20 @@ __global__ __launch_bounds__(256) void k_fold_wave(const Partial *__restrict__ p
                                                    const int2 *__restrict__ ids,
                                                    bioem_hip_prob_map *__restrict__ pmap)
 {
+  static_assert(WPP == 1 || WPP == 4, "one wave or one block per particle");
+  __shared__ double shM[4], shS[4];
+  __shared__ int shI[4];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int p = blockIdx.x * 4 + wave;
+  const int p = WPP == 1 ? blockIdx.x * 4 + wave : blockIdx.x;
   if (p >= nMaps)
     return;
   const Partial *P = partials + (size_t) p * ldPart;
-  const int chunk = (nOC + 63) / 64;
-  const int b = lane * chunk, e = min(nOC, b + chunk);
+  const int nChunks = 64 * WPP;
+  const int chunk = (nOC + nChunks - 1) / nChunks;
+  const int b = min(nOC, (WPP == 1 ? lane : (int) threadIdx.x) * chunk), e = min(nOC, b + chunk);
   double m = -INFINITY, sacc = 0.;
   int idx = 0x7fffffff;
+#pragma unroll 4
   for (int oc = b; oc < e; oc++)
   {
     const Partial r = P[oc];
@@ -146,7 +155,31 @@ __global__ __launch_bounds__(256) void k_fold_wave(const Partial *__restrict__ p
     else
       sacc += (m2 == -INFINITY) ? 0. : s2 * exp(m2 - m);
   }
-  if (lane == 0 && idx != 0x7fffffff)
+  if (WPP == 4)
+  {
+    if (lane == 0)
+    {
+      shM[wave] = m;
+      shS[wave] = sacc;
+      shI[wave] = idx;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0)
+      for (int w = 1; w < 4; w++)
+      {
+        const double m2 = shM[w], s2 = shS[w];
+        const int i2 = shI[w];
+        if (m2 > m || (m2 == m && i2 < idx))
+        {
+          sacc = ((m == -INFINITY) ? 0. : sacc * exp(m - m2)) + s2;
+          m = m2;
+          idx = i2;
+        }
+        else
+          sacc += (m2 == -INFINITY) ? 0. : s2 * exp(m2 - m);
+      }
+  }
+  if (threadIdx.x % (64 * WPP) == 0 && idx != 0x7fffffff)
   {
     bioem_hip_prob_map pm = pmap[p];
     if (pm.Constoadd < m)
