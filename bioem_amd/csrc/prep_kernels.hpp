@@ -360,10 +360,21 @@ __global__ __launch_bounds__(256) void k_project_box(const bioem_hip_model_point
     double td = 0.;
     for (int sweep = 0; sweep < 2; sweep++)
     {
-      // sweep 0: into the box; sweep 1 (only if a point fell outside it): those points into the stored map
-      for (int it = threadIdx.x; it < nPts * S; it += blockDim.x)
+      // sweep 0: into the box; sweep 1 (only if a point fell outside it): those points into the stored map.
+      // Two items per thread and round: both points, then both footprint columns (five stamp entries each) are on
+      // their way before the first is used -- an item alone is a chain of two memory latencies and an LDS atomic.
+      struct Item
       {
-        const int n = it / S, dj = it - n * S - iradMax;
+        bool act, point;
+        int irad;
+        float density;
+        double *dst;
+        const double *st;
+      };
+      auto decode = [&](int it) -> Item {
+        Item q;
+        const bool in = it < nPts * S;
+        const int n = in ? it / S : 0, dj = it - n * S - iradMax;
         const bioem_hip_model_point p = pts[n];
         float rp[3] = {0.f, 0.f, 0.f};
         for (int k = 0; k < 3; k++)
@@ -382,38 +393,61 @@ __global__ __launch_bounds__(256) void k_project_box(const bioem_hip_model_point
           irad = (int) (p.radius / pixelSize) + 1;
           ok = !(i < irad || j < irad || i >= N - irad || j >= N - irad) && dj >= -irad && dj <= irad;
         }
-        if (!ok)
-          continue;
+        ok = ok && in;
         const bool inbox = i - irad >= lo && i + irad <= hi && j - irad >= lo && j + irad <= hi;
-        if (inbox != (sweep == 0))
-        {
-          if (sweep == 0)
-            outside = 1;
-          continue;
-        }
-        double *dst = sweep == 0 ? box + (i - lo) * side + (j + dj - lo) : map + (size_t) i * N + j + dj;
-        const int ld = sweep == 0 ? side : N;
-        if (irad == 0)
+        if (ok && !inbox && sweep == 0)
+          outside = 1;
+        q.act = ok && inbox == (sweep == 0);
+        q.point = irad == 0;
+        q.irad = irad;
+        q.density = p.density;
+        q.dst = sweep == 0 ? box + (i - lo) * side + (j + dj - lo) : map + (size_t) i * N + j + dj;
+        q.st = stamp + ((size_t) n * S + iradMax) * S + dj + iradMax;
+        return q;
+      };
+      const int ld = sweep == 0 ? side : N;
+      auto fetch = [&](const Item &q, int d0, double (&w)[5]) {
+#pragma unroll
+        for (int u = 0; u < 5; u++)
+          w[u] = (q.act && !q.point && d0 + u <= q.irad) ? q.st[(d0 + u) * S] : 0.;
+      };
+      auto splat = [&](const Item &q, int d0, const double (&w)[5]) {
+#pragma unroll
+        for (int u = 0; u < 5; u++)
+          if (w[u] != 0.) // inside the sphere (dist < rad2: the weight is positive there)
+          {
+            atomicAdd(q.dst + (d0 + u) * ld, w[u]);
+            td += w[u];
+          }
+      };
+      for (int it = threadIdx.x; it < nPts * S; it += 2 * blockDim.x)
+      {
+        const Item qa = decode(it), qb = decode(it + blockDim.x);
+        double wa[5], wb[5];
+        fetch(qa, -qa.irad, wa);
+        fetch(qb, -qb.irad, wb);
+        if (qa.act && qa.point)
         { // a point: bioem.cpp:1700-1712
-          atomicAdd(dst, (double) p.density);
-          td += (double) p.density;
-          continue;
+          atomicAdd(qa.dst, (double) qa.density);
+          td += (double) qa.density;
         }
-        // footprint column dj of the sphere: rows i - irad .. i + irad, five stamp entries in flight
-        const double *st = stamp + ((size_t) n * S + iradMax) * S + dj + iradMax;
-        for (int d0 = -irad; d0 <= irad; d0 += 5)
+        if (qb.act && qb.point)
         {
-          double w[5];
-#pragma unroll
-          for (int u = 0; u < 5; u++)
-            w[u] = d0 + u <= irad ? st[(d0 + u) * S] : 0.;
-#pragma unroll
-          for (int u = 0; u < 5; u++)
-            if (w[u] != 0.) // inside the sphere (dist < rad2: the weight is positive there)
-            {
-              atomicAdd(dst + (d0 + u) * ld, w[u]);
-              td += w[u];
-            }
+          atomicAdd(qb.dst, (double) qb.density);
+          td += (double) qb.density;
+        }
+        splat(qa, -qa.irad, wa);
+        splat(qb, -qb.irad, wb);
+        // footprints wider than five pixels: the rest of the column
+        for (int d0 = -qa.irad + 5; d0 <= qa.irad; d0 += 5)
+        {
+          fetch(qa, d0, wa);
+          splat(qa, d0, wa);
+        }
+        for (int d0 = -qb.irad + 5; d0 <= qb.irad; d0 += 5)
+        {
+          fetch(qb, d0, wb);
+          splat(qb, d0, wb);
         }
       }
       __syncthreads(); // every splat of this sweep is done
