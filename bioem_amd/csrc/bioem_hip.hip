@@ -130,6 +130,7 @@ struct bioem_hip_ctx
   bioem_hip_model_point *dPts = nullptr;
   double *dStamp = nullptr; // sphere footprints of the model (k_project_stamps), (2 iradMax + 1)^2 doubles per point
   double modelRadius = 0.;  // max |point| of the model, Angstrom (k_project_box)
+  bool anglesKeepLength = true; // every uploaded quaternion is of unit length (Euler angles always are rotations)
   int nPts = 0;
   float NormDen = 0, pixelSize = 0;
   int shiftX = 0, shiftY = 0;
@@ -613,13 +614,14 @@ hipError_t conv_allow_lds()
 // r2c of nImg images (double projection maps scaled by NormDen / tempden, or float maps) into `out` (reference layout);
 // rowSpec holds the row pass (N x H double2 per image).  dft_allow_lds(N) must have run on this device.
 hipError_t launch_r2c(hipStream_t st, int nCU, const double *srcD, const float *srcF, const double *tempDen, float NormDen,
-                      int N, int nImg, const double2 *tw, double2 *rowSpec, float2 *out)
+                      int N, int nImg, const double2 *tw, double2 *rowSpec, float2 *out, int lo = 0, int side = 0)
 {
+  side = side ? side : N; // (a box smaller than the map: the fast transform only, see project_batch)
   const int H = N / 2 + 1;
   int A, B;
   dft_split(N, A, B);
   if (r2c_use_fft(N))
-    return bioem_r2c_fft_launch(st, nCU, srcD, srcF, tempDen, NormDen, N, nImg, tw, rowSpec, out);
+    return bioem_r2c_fft_launch(st, nCU, srcD, srcF, tempDen, NormDen, N, nImg, tw, rowSpec, out, lo, side);
   if (dft_use_mfma(N))
   {
     // resident grids: as many blocks as the LDS of the device holds at once
@@ -656,9 +658,11 @@ hipError_t launch_r2c(hipStream_t st, int nCU, const double *srcD, const float *
   return hipGetLastError();
 }
 
-int run_r2c(bioem_hip_ctx *h, const BatchBuf &bb, hipStream_t st, const double *srcD, const float *srcF, int nImg)
+int run_r2c(bioem_hip_ctx *h, const BatchBuf &bb, hipStream_t st, const double *srcD, const float *srcF, int nImg,
+            int lo = 0, int side = 0)
 {
-  HIP_CHECK(h, launch_r2c(st, h->nCU, srcD, srcF, bb.tempDen, h->NormDen, h->N, nImg, h->dTwD, bb.rowSpec, bb.specRef));
+  HIP_CHECK(h, launch_r2c(st, h->nCU, srcD, srcF, bb.tempDen, h->NormDen, h->N, nImg, h->dTwD, bb.rowSpec, bb.specRef, lo,
+                          side));
   return 0;
 }
 
@@ -670,14 +674,17 @@ int project_batch(bioem_hip_ctx *h, const BatchBuf &bb, hipStream_t st, int o0, 
   const int boxLo = std::max(0, (int) std::floor(N / 2.0 + 0.5 - reach) - 1 - h->iradMax - std::max(0, std::max(h->shiftX, h->shiftY)));
   const int boxHi = std::min(N - 1, (int) std::floor(N / 2.0 + 0.5 + reach) + 1 + h->iradMax - std::min(0, std::min(h->shiftX, h->shiftY)));
   const int boxSide = boxHi - boxLo + 1;
+  // (orientations that stretch the model -- quaternions that are not of unit length -- take the band kernel)
   if (h->dStamp && boxSide >= 1 && (size_t) boxSide * boxSide * sizeof(double) <= 52 * 1024 && N < 32768 &&
-      !getenv("BIOEM_PROJECT_BANDS") && !getenv("BIOEM_PROJECT_GLOBAL_ATOMICS"))
+      h->anglesKeepLength && !getenv("BIOEM_PROJECT_BANDS") && !getenv("BIOEM_PROJECT_GLOBAL_ATOMICS"))
   {
+    // with the fast r2c behind it the kernel stores the box alone and the transform skips everything outside it
+    const int compact = r2c_use_fft(N) && !getenv("BIOEM_PROJECT_FULL_MAP");
     hipLaunchKernelGGL(k_project_box, dim3(std::min(nO, 3 * h->nCU)), dim3(256), sizeof(double) * boxSide * boxSide, st,
                        h->dPts, h->nPts, h->dAngles, o0, h->isQuat, N, h->pixelSize, h->shiftX, h->shiftY, h->iradMax,
-                       h->dStamp, boxLo, boxSide, nO, bb.projReal, bb.tempDen);
+                       h->dStamp, boxLo, boxSide, nO, compact, bb.projReal, bb.tempDen);
     HIP_CHECK(h, hipGetLastError());
-    return run_r2c(h, bb, st, bb.projReal, nullptr, nO);
+    return compact ? run_r2c(h, bb, st, bb.projReal, nullptr, nO, boxLo, boxSide) : run_r2c(h, bb, st, bb.projReal, nullptr, nO);
   }
   HIP_CHECK(h, hipMemsetAsync(bb.tempDen, 0, sizeof(double) * nO, st)); // (k_project_box writes its sums itself)
   const int TR = 40960 / (8 * N); // rows of one LDS band: three blocks per CU
@@ -1371,6 +1378,21 @@ int bioem_hip_upload_orientations(bioem_hip_handle h, const float *angles4, int 
   HIP_CHECK(h, hipMemcpy(h->dAngles, angles4, sizeof(float4) * (size_t) n, hipMemcpyHostToDevice));
   h->nAnglesUp = n;
   h->isQuat = isQuat;
+  // k_project_box relies on the rotated model staying inside its box: the reference's quaternion matrix
+  // (bioem.cpp:1632-1646) is a rotation only for unit quaternions; a list that stretches the model by more than a
+  // fraction of a pixel takes the band kernel instead
+  h->anglesKeepLength = true;
+  if (isQuat)
+  {
+    const double reach = h->pixelSize > 0.f ? std::max(1.0, h->modelRadius / (double) h->pixelSize) : 1e4;
+    for (int k = 0; k < n && h->anglesKeepLength; k++)
+    {
+      const float *q = angles4 + 4 * (size_t) k;
+      const double n2 = (double) q[0] * q[0] + (double) q[1] * q[1] + (double) q[2] * q[2] + (double) q[3] * q[3];
+      if (!(std::fabs(n2 - 1.0) * 2.0 * reach < 0.25))
+        h->anglesKeepLength = false;
+    }
+  }
   return 0;
 }
 

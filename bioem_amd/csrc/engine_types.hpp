@@ -36,11 +36,12 @@ BIOEM_HIDDEN const BioemKernelEntry *bioem_kernels_wide2_16(int *n);
 BIOEM_HIDDEN const BioemKernelEntry *bioem_kernels_wide2_long(int *n);  // 20..32 points
 BIOEM_HIDDEN const BioemKernelEntry *bioem_kernels_odd(int *n);         // k_compare_rows, k_compare_oddfft
 
-// the fast r2c (kernels_r2c.hip): image sizes N = A * B with both factors at most 20; rowSpec holds the row pass
+// the fast r2c (kernels_r2c.hip): image sizes N = A * B with both factors at most 20; rowSpec holds the row pass.
+// The maps are zero outside [lo, lo + side)^2 and stored as that square only (lo = 0, side = N: whole maps).
 BIOEM_HIDDEN bool bioem_r2c_fft_supported(int N);
 BIOEM_HIDDEN hipError_t bioem_r2c_fft_launch(hipStream_t st, int nCU, const double *srcD, const float *srcF,
                                              const double *tempDen, float NormDen, int N, int nImg, const double2 *tw,
-                                             double2 *rowSpec, float2 *out);
+                                             double2 *rowSpec, float2 *out, int lo, int side);
 
 enum KernelFamily
 {

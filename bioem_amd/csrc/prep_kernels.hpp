@@ -333,17 +333,18 @@ __global__ __launch_bounds__(256) void k_project_bands(const ProjectRecord *__re
 // rotation, pixel, the reference's skip rules as in k_project_coords, the footprint from the stamps -- and the whole
 // map (zeros around the box) is stored once.  Against k_project_coords + k_project_bands there is no record list, no
 // band that scans all points to find its few, and no barrier between zeroing and storing; tempden is the block's own
-// sum.  A point that passes the reference's rules but falls outside the box (a quaternion that is not of unit length
-// stretches the model) is added to the stored map with global atomics in a second sweep.
+// sum.  COMPACT: only the box is stored, [ob][side][side] (the fast r2c skips what lies outside); else the whole map.
+// The host guarantees that no point leaves the box (unit quaternions only, bioem_hip_upload_orientations); one that
+// did would be dropped.
 __global__ __launch_bounds__(256) void k_project_box(const bioem_hip_model_point *__restrict__ pts, int nPts,
                                                       const float4 *__restrict__ angles, int o0, int isQuat, int N,
                                                       float pixelSize, int shiftX, int shiftY, int iradMax,
                                                       const double *__restrict__ stamp, int lo, int side, int nO,
-                                                      double *__restrict__ proj, double *__restrict__ tempden)
+                                                      int compact, double *__restrict__ proj,
+                                                      double *__restrict__ tempden)
 {
   extern __shared__ double box[]; // side x side
   __shared__ double red[4];
-  __shared__ int outside;
   const int S = 2 * iradMax + 1;
   const int hi = lo + side - 1;
   for (int ob = blockIdx.x; ob < nO; ob += gridDim.x)
@@ -351,16 +352,11 @@ __global__ __launch_bounds__(256) void k_project_box(const bioem_hip_model_point
     __syncthreads(); // the previous map is stored
     for (int e = threadIdx.x; e < side * side; e += blockDim.x)
       box[e] = 0.;
-    if (threadIdx.x == 0)
-      outside = 0;
     float rotmat[3][3];
     rotation_matrix(angles[o0 + ob], isQuat, rotmat);
-    double *map = proj + (size_t) ob * N * N;
     __syncthreads();
     double td = 0.;
-    for (int sweep = 0; sweep < 2; sweep++)
     {
-      // sweep 0: into the box; sweep 1 (only if a point fell outside it): those points into the stored map.
       // Two items per thread and round: both points, then both footprint columns (five stamp entries each) are on
       // their way before the first is used -- an item alone is a chain of two memory latencies and an LDS atomic.
       struct Item
@@ -395,17 +391,15 @@ __global__ __launch_bounds__(256) void k_project_box(const bioem_hip_model_point
         }
         ok = ok && in;
         const bool inbox = i - irad >= lo && i + irad <= hi && j - irad >= lo && j + irad <= hi;
-        if (ok && !inbox && sweep == 0)
-          outside = 1;
-        q.act = ok && inbox == (sweep == 0);
+        q.act = ok && inbox;
         q.point = irad == 0;
         q.irad = irad;
         q.density = p.density;
-        q.dst = sweep == 0 ? box + (i - lo) * side + (j + dj - lo) : map + (size_t) i * N + j + dj;
+        q.dst = box + (i - lo) * side + (j + dj - lo);
         q.st = stamp + ((size_t) n * S + iradMax) * S + dj + iradMax;
         return q;
       };
-      const int ld = sweep == 0 ? side : N;
+      const int ld = side;
       auto fetch = [&](const Item &q, int d0, double (&w)[5]) {
 #pragma unroll
         for (int u = 0; u < 5; u++)
@@ -450,18 +444,21 @@ __global__ __launch_bounds__(256) void k_project_box(const bioem_hip_model_point
           splat(qb, d0, wb);
         }
       }
-      __syncthreads(); // every splat of this sweep is done
-      if (sweep == 0)
+      __syncthreads(); // every splat is done
+      if (compact)
       {
+        double *dst = proj + (size_t) ob * side * side;
+        for (int e = threadIdx.x; e < side * side; e += blockDim.x)
+          dst[e] = box[e];
+      }
+      else
+      {
+        double *map = proj + (size_t) ob * N * N;
         for (int e = threadIdx.x; e < N * N; e += blockDim.x)
         {
           const int r = e / N, c = e - r * N;
           map[e] = (r >= lo && r <= hi && c >= lo && c <= hi) ? box[(r - lo) * side + c - lo] : 0.;
         }
-        if (!outside)
-          break;
-        __threadfence();
-        __syncthreads();
       }
     }
     for (int o = 32; o > 0; o >>= 1)

@@ -9,7 +9,9 @@
 //   stage 2   thread (g, kb):  Z[kb + B m] = FFT_A over j1 of Y[j1][kb]
 // Row pass: two image rows per complex transform (z = row_i + i row_(i+1)), separated on the way out
 // (X_i[k] = (Z[k] + conj Z[N-k]) / 2, X_(i+1)[k] = (Z[k] - conj Z[N-k]) / 2i); its result is left transposed,
-// spec[b][k][i], as the matrix kernels leave it.  Column pass: one spectrum column per transform, result rounded to
+// spec[b][k][i], as the matrix kernels leave it (i over the rows that are not zero: projections arrive as the box of
+// pixels the model can reach, a third of the map's side at BASELINE's sizes, and everything outside it is skipped --
+// rows not transformed, zeros not moved).  Column pass: one spectrum column per transform, result rounded to
 // float in the reference layout out[b][u][k].  Everything between the float input and the float output is double, so
 // the result is the correctly rounded spectrum but for ~1e-16 relative (the DFT kernels: the same); the two paths agree
 // to the last float bit in all but a few values per million.
@@ -250,6 +252,10 @@ struct R2cArgs
   float2 *out;           // column pass: reference layout [b][u][k]
   const double2 *twD;    // exp(+2 pi i j / N), j < N
   int N, H, A, B, nImg;
+  // the input is zero outside the square [lo, lo + side)^2 and srcD holds that square only, [b][side][side] (the box of
+  // k_project_box; lo = 0, side = N: whole maps): the row pass transforms the `side` rows that are not zero, the
+  // intermediate is [b][k][side], the column pass reads zeros for the other rows
+  int lo, side;
   int G;                 // transforms per unit (block iteration)
   int YG;                // doubles per transform in a Y plane, = B (mod 32): stage 2 reads without bank conflicts
   int Gp;                // odd row length of the transposed Z planes
@@ -265,20 +271,25 @@ __device__ __forceinline__ void r2c_stage1(const R2cArgs &a, const double2 *tw, 
   double re[B], im[B];
   const int N = a.N, A = a.A;
   item = item < nItems ? item : nItems - 1;
+  const int lo = a.lo, side = a.side;
   if constexpr (ROWS)
   {
-    const int NP = (N + 1) >> 1;
+    const int NP = (side + 1) >> 1; // pairs of rows lo + 2 r, lo + 2 r + 1
     const int b = (int) (item / NP), i = 2 * (int) (item - (long) b * NP);
-    const int second = i + 1 < N ? N : 0; // odd N: the last row is paired with itself, the copy is dropped on the way out
-    const size_t r0 = ((size_t) b * N + i) * N + j1;
+    const int second = i + 1 < side ? side : 0; // odd: the last row is paired with itself, the copy is dropped on the way out
+    const size_t r0 = ((size_t) b * side + i) * side;
     if (a.srcD)
     {
       const float ratio = a.NormDen / (float) a.tempden[b]; // bioem.cpp:1808-1818
 #pragma unroll
       for (int j2 = 0; j2 < B; j2++)
       {
-        re[j2] = (double) ((float) a.srcD[r0 + A * j2] * ratio);
-        im[j2] = (double) ((float) a.srcD[r0 + second + A * j2] * ratio);
+        const int j = A * j2 + j1 - lo;
+        const bool in = (unsigned) j < (unsigned) side;
+        const size_t e = r0 + (in ? j : 0);
+        const float v0 = (float) a.srcD[e] * ratio, v1 = (float) a.srcD[e + second] * ratio;
+        re[j2] = in ? (double) v0 : 0.;
+        im[j2] = in ? (double) v1 : 0.;
       }
     }
     else
@@ -286,20 +297,25 @@ __device__ __forceinline__ void r2c_stage1(const R2cArgs &a, const double2 *tw, 
 #pragma unroll
       for (int j2 = 0; j2 < B; j2++)
       {
-        re[j2] = (double) a.srcF[r0 + A * j2];
-        im[j2] = (double) a.srcF[r0 + second + A * j2];
+        const int j = A * j2 + j1 - lo;
+        const bool in = (unsigned) j < (unsigned) side;
+        const size_t e = r0 + (in ? j : 0);
+        re[j2] = in ? (double) a.srcF[e] : 0.;
+        im[j2] = in ? (double) a.srcF[e + second] : 0.;
       }
     }
   }
   else
   {
-    const size_t r0 = (size_t) item * N + j1; // item = b * H + k
+    const size_t r0 = (size_t) item * side; // item = b * H + k
 #pragma unroll
     for (int j2 = 0; j2 < B; j2++)
     {
-      const double2 v = a.specIn[r0 + A * j2];
-      re[j2] = v.x;
-      im[j2] = v.y;
+      const int i = A * j2 + j1 - lo;
+      const bool in = (unsigned) i < (unsigned) side;
+      const double2 v = a.specIn[r0 + (in ? i : 0)];
+      re[j2] = in ? v.x : 0.;
+      im[j2] = in ? v.y : 0.;
     }
   }
   r2c_fft_fwd<B>(re, im);
@@ -358,7 +374,7 @@ __global__ __launch_bounds__(kR2cThreads, NBLK) void k_r2c_fft(const R2cArgs a)
   const int N = a.N, H = a.H, A = a.A, B = a.B, G = a.G;
   for (int j = t; j < N; j += kR2cThreads)
     tw[j] = a.twD[j];
-  const int perImg = ROWS ? (N + 1) >> 1 : H;
+  const int perImg = ROWS ? (a.side + 1) >> 1 : H;
   const long nItems = (long) a.nImg * perImg;
   const int nUnits = (int) ((nItems + G - 1) / G);
   const int g1h = t / A, j1h = t - g1h * A;
@@ -398,7 +414,7 @@ __global__ __launch_bounds__(kR2cThreads, NBLK) void k_r2c_fft(const R2cArgs a)
     __syncthreads();
     if constexpr (ROWS)
     {
-      const int NP = (N + 1) >> 1;
+      const int NP = (a.side + 1) >> 1;
       for (int idx = t; idx < G * H; idx += kR2cThreads)
       {
         const int k = idx / G, g = idx - k * G;
@@ -409,9 +425,9 @@ __global__ __launch_bounds__(kR2cThreads, NBLK) void k_r2c_fft(const R2cArgs a)
         const int k2 = k ? N - k : 0;
         const double zr = Pr[k * a.Gp + g], zi = Pi[k * a.Gp + g];
         const double yr = Pr[k2 * a.Gp + g], yi = Pi[k2 * a.Gp + g];
-        double2 *dst = a.specOut + ((size_t) b * H + k) * N + i;
+        double2 *dst = a.specOut + ((size_t) b * H + k) * a.side + i;
         dst[0] = make_double2(0.5 * (zr + yr), 0.5 * (zi - yi));
-        if (i + 1 < N)
+        if (i + 1 < a.side)
           dst[1] = make_double2(0.5 * (zi + yi), 0.5 * (yr - zr));
       }
     }

@@ -29,6 +29,13 @@ def _ensure_built():
 
 def pytest_sessionstart(session):
     _ensure_built()
+    # PyTorch first: the RCCL tests need the process to hold PyTorch's copy of RCCL / the HSA runtime before
+    # libbioem_hip.so brings in the system's (loaded the other way round, ncclCommInitAll finds "no ROCm-capable
+    # device" -- seen when tests/test_gpu_parity.py ran on its own, where no earlier file had imported torch)
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     # every engine handle created during the run (this process and the CLI children) records the comparison-kernel
     # instantiation it selected: scripts/check_kernel_coverage.py compares the record with the code object
     log = os.path.join(ROOT, "gpurun_out", "kernel_signatures_run.txt")
