@@ -600,15 +600,18 @@ hipError_t dft_allow_lds(int N)
                              (int) dft_cols_lds(N));
 }
 
-// k_convolve_sums keeps two tiles of terms for six CTFs per orientation in dynamic LDS: 45 KiB per orientation of a block
+// k_convolve_sums keeps two tiles of terms for up to 20 (orientation, CTF) chains in dynamic LDS: 151 KiB
 hipError_t conv_allow_lds()
 {
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_convolve_sums<2>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int) conv_lds_bytes<2>());
-  if (e != hipSuccess)
-    return e;
-  return hipFuncSetAttribute(reinterpret_cast<const void *>(k_convolve_sums<3>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                             (int) conv_lds_bytes<3>());
+  const void *fns[3] = {reinterpret_cast<const void *>(k_convolve_sums<3>), reinterpret_cast<const void *>(k_convolve_sums<4>),
+                        reinterpret_cast<const void *>(k_convolve_sums<5>)};
+  for (const void *f : fns)
+  {
+    const hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int) conv_lanes_lds(kLaneRows));
+    if (e != hipSuccess)
+      return e;
+  }
+  return hipSuccess;
 }
 
 // r2c of nImg images (double projection maps scaled by NormDen / tempden, or float maps) into `out` (reference layout);
@@ -813,18 +816,20 @@ int convolve_batch(bioem_hip_ctx *h, const BatchBuf &bb, hipStream_t st, int nO,
   const char *fe = getenv("BIOEM_CONVOLVE_FUSED");
   if (fe ? atoi(fe) != 0 : h->nMaps <= 64)
   {
-    const char *je = getenv("BIOEM_CONVOLVE_J"); // orientations per block (1, 2, 3): timing experiments
-    const int J = je ? atoi(je) : 2;
+    // chains on the lanes of the adding wave: as many orientations per block as 20 chains of two tiles fit in LDS
     const int nCg = (nC + kConvCtfs - 1) / kConvCtfs;
-    if (J == 1)
-      hipLaunchKernelGGL(k_convolve_sums<1>, dim3(nCg, nO), dim3(kConvThreads), conv_lds_bytes<1>(), st, bb.specRef, h->dCTF,
-                         h->dCtfParam, h->N, h->H, h->fast, h->N1, c0, nC, nO, bb.conv, bb.params);
-    else if (J == 3)
-      hipLaunchKernelGGL(k_convolve_sums<3>, dim3(nCg, (nO + 2) / 3), dim3(kConvThreads), conv_lds_bytes<3>(), st, bb.specRef,
-                         h->dCTF, h->dCtfParam, h->N, h->H, h->fast, h->N1, c0, nC, nO, bb.conv, bb.params);
+    const int nCb = std::min(nC, kConvCtfs);
+    const int R = std::max(3, std::min(5, kLaneRows / nCb)), rows = std::min(kLaneRows, R * nCb);
+    const dim3 grid(nCg, (nO + R - 1) / R);
+    if (R == 3)
+      hipLaunchKernelGGL(k_convolve_sums<3>, grid, dim3(kConvThreads), conv_lanes_lds(rows), st, bb.specRef, h->dCTF,
+                         h->dCtfParam, h->N, h->H, h->fast, h->N1, c0, nC, nO, rows, bb.conv, bb.params);
+    else if (R == 4)
+      hipLaunchKernelGGL(k_convolve_sums<4>, grid, dim3(kConvThreads), conv_lanes_lds(rows), st, bb.specRef, h->dCTF,
+                         h->dCtfParam, h->N, h->H, h->fast, h->N1, c0, nC, nO, rows, bb.conv, bb.params);
     else
-      hipLaunchKernelGGL(k_convolve_sums<2>, dim3(nCg, (nO + 1) / 2), dim3(kConvThreads), conv_lds_bytes<2>(), st, bb.specRef,
-                         h->dCTF, h->dCtfParam, h->N, h->H, h->fast, h->N1, c0, nC, nO, bb.conv, bb.params);
+      hipLaunchKernelGGL(k_convolve_sums<5>, grid, dim3(kConvThreads), conv_lanes_lds(rows), st, bb.specRef, h->dCTF,
+                         h->dCtfParam, h->N, h->H, h->fast, h->N1, c0, nC, nO, rows, bb.conv, bb.params);
     HIP_CHECK(h, hipGetLastError());
     return 0;
   }

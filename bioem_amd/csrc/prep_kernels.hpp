@@ -784,10 +784,10 @@ __global__ __launch_bounds__(64) void k_parseval_ordered(const float *__restrict
 
 // ------------------------------------------------------------------------------------------------
 // k_convolve_sums: the two kernels above in one -- no Parseval terms through global memory.
-// One block per (orientation, group of up to kConvCtfs CTFs).  Waves 1..15 form the products of a tile of kConvTile
+// One block per (R orientations, group of up to kConvCtfs CTFs).  Waves 1..15 form the products of a tile of kConvTile
 // consecutive positions of the reference's summation order for every CTF of the group (the projection element is read
-// once), store the spectra and leave the terms in LDS; wave 0 adds the previous tile meanwhile, one lane per CTF, one
-// term after the other as the reference does.  In the comparison layout a 16-byte word holds the rows kx and kx + N1:
+// once), store the spectra and leave the terms in LDS; wave 0 adds the previous tile meanwhile, one lane per
+// (orientation, CTF), one term after the other as the reference does.  In the comparison layout a 16-byte word holds the rows kx and kx + N1:
 // it is written when the first of them comes by (its partner's product is formed there for the store, and once more
 // when its own position in the order is reached: same operands, same bits).
 // ------------------------------------------------------------------------------------------------
@@ -799,33 +799,37 @@ constexpr int kConvThreads = 1024; // one adding wave, fifteen producing waves
 // per thread change nothing: the adding wave is the longer side.)
 constexpr int kConvTile = kConvThreads - 64;
 constexpr int kConvStride = kConvTile + 4; // chain stride in LDS (floats): the adding lanes read different banks
-// J orientations per block: the adding wave carries their chains side by side (independent additions between the
-// dependent ones), the producers read the CTFs once for all of them.  Measured alone, 5 CTFs at 224^2, block time
-// 130 / 200 / 265 us for J = 1 / 2 / 3 whatever the number of blocks up to one per CU; two J = 1 blocks on a CU take
-// twice as long as one.  Timing-only builds priced the parts of a J = 1 block on an otherwise idle chip: no stores
-// 130 -> 127 us, no CTF loads 130 -> 134, no additions 130 -> 73 (with every CU busy 139 -> 126: the producers then
-// take as long as the chain); 32, 64 or 128 terms in flight from LDS, or the adding wave alone on its SIMD, change
-// nothing.  Whole jobs of 10...20 particles: J = 2 is 3 % ahead of J = 1; J = 3 wins where it saves a round of blocks
-// (768 orientations x 5 CTFs: +4 %) and loses elsewhere (-4 %): J = 2 it is (BIOEM_CONVOLVE_J overrides).
-template <int J>
-constexpr size_t conv_lds_bytes() { return sizeof(float) * 2 * J * kConvCtfs * kConvStride; }
-
 // block barrier that orders LDS traffic only: __syncthreads() would also wait for the spectra on their way to memory
 __device__ inline void lds_barrier()
 {
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
-template <int J>
+// A block takes R orientations, their chains (R x CTFs <= 20: two tiles of 960 terms each in 160 KiB of LDS) on the
+// LANES of the adding wave: its instruction stream is the one of a single orientation whatever R is -- one dependent
+// addition every ~12 cycles, 130...150 us per block at 224^2 -- and a producing thread forms the products of its position
+// for the R orientations, the CTF values read once.  Round 4, in the order measured (5 CTFs at 224^2, alone):
+//   one orientation per block (round 3, tiles of 1 024 = a second round trip for 64 positions)  233 us per 256 orientations
+//   tiles of 960                                                                                  132
+//   two / three orientations as interleaved instructions of the adding wave: 200 / 265 us per block (130 for one)
+//   chains on lanes, tiles of 240 positions, 12 orientations per block: the producers' round trip (4.3 us) per 1 us of
+//     additions, 455 us per block; tiles of 960, 4 orientations: 152 us per block
+//   a second operand set fetched a tile ahead: 137 us for 3 orientations (128 registers hold no more)
+// Timing-only builds of a one-orientation block on an otherwise idle chip: no stores 130 -> 127 us, no CTF loads 134,
+// no additions 73; 32, 64 or 128 terms in flight from LDS, or the adding wave alone on its SIMD, change nothing.
+constexpr int kLaneRows = 20;
+inline size_t conv_lanes_lds(int rows) { return sizeof(float) * 2 * rows * kConvStride; }
+
+template <int R>
 __global__ __launch_bounds__(kConvThreads) void
 k_convolve_sums(const float2 *__restrict__ proj, const float2 *__restrict__ ctf, const float *__restrict__ ctfParam,
-                int N, int H, int fast, int N1, int c0, int nC, int nO, float2 *__restrict__ conv,
-                bioem_hip_param5 *__restrict__ params)
+                 int N, int H, int fast, int N1, int c0, int nC, int nO, int rows, float2 *__restrict__ conv,
+                 bioem_hip_param5 *__restrict__ params)
 {
-  extern __shared__ __align__(16) float terms[]; // [2][J][kConvCtfs][kConvStride]
-  __shared__ float sC[J][kConvCtfs];
-  const int ob0 = blockIdx.y * J, cg = blockIdx.x * kConvCtfs;
-  const int nJ = min(J, nO - ob0);
+  extern __shared__ __align__(16) float terms[]; // [2][rows][kConvStride], rows >= R x CTFs of the block
+  __shared__ float sC[kLaneRows];
+  const int ob0 = blockIdx.y * R, cg = blockIdx.x * kConvCtfs;
+  const int nJ = min(R, nO - ob0);
   const int nCb = min(kConvCtfs, nC - cg);
   const int M = N * H;
   const int even = ((N & 1) == 0);
@@ -833,136 +837,136 @@ k_convolve_sums(const float2 *__restrict__ proj, const float2 *__restrict__ ctf,
   const float2 *K0 = ctf + (size_t) (c0 + cg) * M;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int nt = (M + kConvTile - 1) / kConvTile;
-  auto produce = [&](int t) {
-    float *T = terms + (size_t) (t & 1) * J * kConvCtfs * kConvStride;
-    const int e = (int) threadIdx.x - 64;
+  const int e = (int) threadIdx.x - 64; // producers: position in the tile
+  // what a producing thread holds of one tile: the operands of its position and where the results go
+  struct Operands
+  {
+    float2 p[R], p1[R], kv[kConvCtfs], k1[kConvCtfs];
+    int ij, word; // (a spectrum has fewer than 2^31 elements: kMaxPixels)
+    bool valid, twice, first, origin;
+  };
+  auto fetch = [&](int t, Operands &L) {
     const int pos0 = t * kConvTile + e;
-    const bool valid = pos0 < M; // beyond the spectrum: the last element is read, a zero term left, nothing stored
-    const int pos = valid ? pos0 : M - 1;
+    L.valid = pos0 < M; // beyond the spectrum: the last element is read, a zero term left, nothing stored
+    const int pos = L.valid ? pos0 : M - 1;
     const int i = pos / H, r = pos - i * H;
     const int j = r < jend - 1 ? r + 1 : (r == jend - 1 ? 0 : H - 1);
-    const bool twice = j >= 1 && j < jend;
-    const size_t ij = (size_t) i * H + j;
-    bool first = false;
-    size_t word = 0, partner = ij;
+    L.twice = j >= 1 && j < jend;
+    L.origin = i == 0 && j == 0;
+    L.ij = i * H + j;
+    L.first = false;
+    L.word = 0;
+    int partner = L.ij;
     if (fast)
     {
       const int k2 = i / N1, k1i = i - k2 * N1;
-      first = !(k2 & 1);
-      word = (size_t) (k1i * fast + (k2 >> 1)) * H + j;
-      partner = first ? ij + (size_t) N1 * H : ij;
+      L.first = !(k2 & 1);
+      L.word = (k1i * fast + (k2 >> 1)) * H + j;
+      partner = L.first ? L.ij + N1 * H : L.ij;
     }
-    // every load of the tile first ...
-    float2 p[J], p1[J], kv[kConvCtfs], k1[kConvCtfs];
 #pragma unroll
-    for (int o = 0; o < J; o++)
+    for (int q = 0; q < R; q++)
     {
-      const float2 *P = proj + (size_t) (ob0 + min(o, nJ - 1)) * M;
-      p[o] = P[ij];
-      p1[o] = P[partner];
+      const float2 *P = proj + (size_t) (ob0 + min(q, nJ - 1)) * M;
+      L.p[q] = P[L.ij];
+      L.p1[q] = P[partner];
     }
 #pragma unroll
     for (int c = 0; c < kConvCtfs; c++)
       if (c < nCb)
       {
         const float2 *Kc = K0 + (size_t) c * M;
-        kv[c] = Kc[ij];
-        k1[c] = Kc[partner];
+        L.kv[c] = Kc[L.ij];
+        L.k1[c] = Kc[partner];
       }
-    // ... then the products, the terms and the stores
+  };
+  auto produce = [&](int t, const Operands &L) {
+    float *T = terms + (size_t) (t & 1) * rows * kConvStride;
 #pragma unroll
-    for (int o = 0; o < J; o++)
+    for (int q = 0; q < R; q++)
     {
-      if (o >= nJ)
+      if (q >= nJ)
         break;
-      float2 *O0 = conv + ((size_t) (ob0 + o) * nC + cg) * M;
+      float2 *O0 = conv + ((size_t) (ob0 + q) * nC + cg) * M;
 #pragma unroll
       for (int c = 0; c < kConvCtfs; c++)
         if (c < nCb)
         {
           float2 *O = O0 + (size_t) c * M;
-          const float2 k = kv[c];
+          const float2 k = L.kv[c];
           float2 v;
-          v.x = (p[o].x * k.x + p[o].y * k.y);
-          v.y = (p[o].y * k.x - p[o].x * k.y);
+          v.x = (L.p[q].x * k.x + L.p[q].y * k.y);
+          v.y = (L.p[q].y * k.x - L.p[q].x * k.y);
           const float tt = v.x * v.x + v.y * v.y;
-          T[(o * kConvCtfs + c) * kConvStride + e] = valid ? (twice ? tt * 2 : tt) : 0.f; // x + 0 = x
-          if (!valid)
+          T[(q * nCb + c) * kConvStride + e] = L.valid ? (L.twice ? tt * 2 : tt) : 0.f; // x + 0 = x
+          if (!L.valid)
             continue;
           if (!fast)
-            O[ij] = v;
-          else if (first)
+            O[L.ij] = v;
+          else if (L.first)
           {
-            const float2 k1v = k1[c];
+            const float2 k1v = L.k1[c];
             float2 v1;
-            v1.x = (p1[o].x * k1v.x + p1[o].y * k1v.y);
-            v1.y = (p1[o].y * k1v.x - p1[o].x * k1v.y);
-            reinterpret_cast<float4 *>(O)[word] = make_float4(v.x, v.y, v1.x, v1.y);
+            v1.x = (L.p1[q].x * k1v.x + L.p1[q].y * k1v.y);
+            v1.y = (L.p1[q].y * k1v.x - L.p1[q].x * k1v.y);
+            reinterpret_cast<float4 *>(O)[L.word] = make_float4(v.x, v.y, v1.x, v1.y);
           }
-          if (i == 0 && j == 0)
-            sC[o][c] = v.x;
+          if (L.origin)
+            sC[q * nCb + c] = v.x;
         }
     }
   };
+  float ss = 0.f;
+  auto add_tile = [&](int t) {
+    if (lane < nJ * nCb)
+    {
+      const float4 *q = reinterpret_cast<const float4 *>(terms + ((size_t) (t & 1) * rows + lane) * kConvStride);
+      const int n4 = (min(kConvTile, M - t * kConvTile) + 3) >> 2; // the last tile ends with the spectrum
+#pragma unroll 4
+      for (int k = 0; k < n4; k++)
+      {
+        // one term after the other as the reference does (bioem.cpp:1896-1914)
+        const float4 v = q[k];
+        ss += v.x;
+        ss += v.y;
+        ss += v.z;
+        ss += v.w;
+      }
+    }
+  };
+  // (fetching tile t + 2 before the products of tile t + 1 are formed -- a second set of operands -- fits 128 registers
+  // for three orientations only and buys 10 %: 137 against 152 us per block; four or five per block are worth more)
+  Operands A;
   if (wave != 0)
-    produce(0);
+  {
+    fetch(0, A);
+    produce(0, A);
+  }
   else
     __builtin_amdgcn_s_setprio(3); // the adding wave is the critical path: it issues ahead of the producers of its SIMD
   lds_barrier();
-  float ss[J];
-#pragma unroll
-  for (int o = 0; o < J; o++)
-    ss[o] = 0.f;
   for (int t = 0; t < nt; t++)
   {
     if (wave == 0)
-    {
-      if (lane < nCb)
-      {
-        const float *T = terms + (size_t) (t & 1) * J * kConvCtfs * kConvStride;
-        const int n4 = (min(kConvTile, M - t * kConvTile) + 3) >> 2; // the last tile ends with the spectrum
-#pragma unroll 4
-        for (int k = 0; k < n4; k++)
-        {
-          float4 v[J];
-#pragma unroll
-          for (int o = 0; o < J; o++)
-            v[o] = reinterpret_cast<const float4 *>(T + (size_t) (o * kConvCtfs + lane) * kConvStride)[k];
-          // one term after the other as the reference does (bioem.cpp:1896-1914), the J chains interleaved
-#pragma unroll
-          for (int o = 0; o < J; o++)
-            ss[o] += v[o].x;
-#pragma unroll
-          for (int o = 0; o < J; o++)
-            ss[o] += v[o].y;
-#pragma unroll
-          for (int o = 0; o < J; o++)
-            ss[o] += v[o].z;
-#pragma unroll
-          for (int o = 0; o < J; o++)
-            ss[o] += v[o].w;
-        }
-      }
-    }
+      add_tile(t);
     else if (t + 1 < nt)
-      produce(t + 1);
+    {
+      fetch(t + 1, A);
+      produce(t + 1, A);
+    }
     lds_barrier();
   }
-  if (wave == 0 && lane < nCb)
+  if (wave == 0 && lane < nJ * nCb)
   {
-    const int c = c0 + cg + lane;
-#pragma unroll
-    for (int o = 0; o < J; o++)
-      if (o < nJ)
-      {
-        bioem_hip_param5 r;
-        r.amp = ctfParam[3 * c + 0];
-        r.pha = ctfParam[3 * c + 1];
-        r.env = ctfParam[3 * c + 2];
-        r.sumC = sC[o][lane];
-        r.sumsquareC = ss[o] / (float) (N * N);
-        params[(size_t) (ob0 + o) * nC + cg + lane] = r;
-      }
+    const int o = lane / nCb, cl = lane - o * nCb;
+    const int c = c0 + cg + cl;
+    bioem_hip_param5 r;
+    r.amp = ctfParam[3 * c + 0];
+    r.pha = ctfParam[3 * c + 1];
+    r.env = ctfParam[3 * c + 2];
+    r.sumC = sC[lane];
+    r.sumsquareC = ss / (float) (N * N);
+    params[(size_t) (ob0 + o) * nC + cg + cl] = r;
   }
 }
 
