@@ -1520,9 +1520,13 @@ int bioem_hip_project_convolve_compare_ctf(bioem_hip_handle h, int iOrientBegin,
   // (20 particles x 2 304 orientations in 3 batches of 1 060: 11.5 ms per pass, a third of it the exposed first batch;
   // a ramp -- first batches a quarter and a half of the rest -- was measured too: 8.9 against 8.5 ms, more launches
   // cost more than the shorter exposed preparation saves)
-  // ... as long as a batch still compares ~32 000 pairs (a job of 23 000 pairs -- BASELINE config 1 -- is one batch:
-  // 1.1 ms against 1.5 ms in six)
-  const int perBatch = (int) std::min<long long>(h->OB, (32768 + (long long) nC * h->nMaps - 1) / ((long long) nC * h->nMaps));
+  // ... as long as a batch still compares 33 000 ... 65 000 pairs (a job of 23 000 pairs -- BASELINE config 1 -- is one batch:
+  // 0.46 ms against 0.57 ms in two)
+  // (round 4, with the preparation 2.5x faster than when 32 768 was chosen: 65 536 pairs per batch at least for small
+  // images -- 128^2 x 10 particles x 4 608 orientations 63.7 -> 66.2 M/s, x 1 152: 52.5 -> 57.5; 131 072 the same,
+  // 16 384 and less lose; at 224^2 32 768 stays: 10 particles 28.6 against 27.3 M/s with 65 536)
+  const long long minPairs = getenv("BIOEM_MIN_BATCH_PAIRS") ? atoll(getenv("BIOEM_MIN_BATCH_PAIRS")) : (h->N <= 160 ? 65536 : 32768);
+  const int perBatch = (int) std::min<long long>(h->OB, (minPairs + (long long) nC * h->nMaps - 1) / ((long long) nC * h->nMaps));
   const int OBc = std::min(h->OB, std::max(std::max(64, perBatch), (iOrientEnd - iOrientBegin + 5) / 6));
   // (Round 4 measured batches that shrink towards the END as well -- a half, a quarter of the regular size, so that
   // the last comparison, which nothing overlaps, is short: 7.12 -> 7.66 ms per pass at 20 particles, 0.58 -> 0.74 ms
