@@ -4,14 +4,17 @@
 // Hot path (replaces bioem_cuda::compareRefMaps + cuFFT, /root/reference/bioem_cuda.cu:527-684, and the
 // host-side createProjection / createConvolutedProjectionMap, /root/reference/bioem.cpp:1604-1923):
 //
-//   prep_kernels.hpp     k_project_coords, k_project_bands  model points -> real-space projection: one record per
-//                          (orientation, point), bands of map rows in LDS (ds_add_f64), one store; k_project (global
-//                          double atomics) beyond 426 pixels
+//   prep_kernels.hpp     k_project_stamps, k_project_box  model points -> real-space projection: the spheres' footprints
+//                          tabulated once per model, one block per orientation with the box of pixels the model can reach
+//                          in LDS (ds_add_f64), the box stored; k_project_coords + k_project_bands (records, bands of map
+//                          rows in LDS) for models beyond the box, k_project (global double atomics) beyond 426 pixels
 //                        k_convolve       proj * conj(CTF) -> conv spectra in the comparison layout, sumC, Parseval terms
 //                        k_parseval_ordered  sumsquareC: the reference's sequential float sum, four chains per wave
-//                        k_convolve_sums  the two in one kernel (64 particles or fewer)
+//                        k_convolve_sums  the two in one kernel (64 particles or fewer), 3...5 orientations per block
 //                        k_dft_rows/cols  r2c by exact DFT on the vector units (images beyond 304 pixels)
-//   dft_mfma.hpp         k_dft_rows_mfma / k_dft_cols_mfma  r2c of the projections and particle maps: the same exact DFT
+//   r2c_fft.hpp          k_r2c_fft        r2c of the projections and particle maps (kernels_r2c.hip): one Cooley-Tukey split,
+//                          register FFTs of 2...20 points in double; the rows of the projection's box only
+//   dft_mfma.hpp         k_dft_rows_mfma / k_dft_cols_mfma  the r2c of image sizes with a prime factor above 19: exact DFT
 //                          (double accumulation) as v_mfma_f64_16x16x4_f64 products
 //                        k_reorder, k_map_sums: particle-side precompute
 //   compare_fast.hpp     k_compare_fast   windows of at most 21 rows; one WAVE per (particle, orientation*CTF) comparison:
@@ -40,7 +43,8 @@
 //   this file            device context, launch logic, the C ABI
 //   kernels_*.hip        one translation unit per comparison-kernel family (the instantiations of kernel_table.inc),
 //                          linked into the same library: kernels_fast, kernels_fastm, kernels_wide2_{short,16,long},
-//                          kernels_odd; this file keeps the generic kernel, the preparation, fold and merge kernels
+//                          kernels_odd; kernels_r2c: the fast r2c; this file keeps the generic kernel, the preparation,
+//                          fold and merge kernels
 //
 // Numerics: float expressions that the reference evaluates in float are written in the same order and the
 // file is compiled with -ffp-contract=off (FMAs only where fmaf() is spelled out).  Sums that the reference
