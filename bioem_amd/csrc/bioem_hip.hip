@@ -607,8 +607,8 @@ hipError_t dft_allow_lds(int N)
 // k_convolve_sums keeps two tiles of terms for up to 20 (orientation, CTF) chains in dynamic LDS: 151 KiB
 hipError_t conv_allow_lds()
 {
-  const void *fns[3] = {reinterpret_cast<const void *>(k_convolve_sums<3>), reinterpret_cast<const void *>(k_convolve_sums<4>),
-                        reinterpret_cast<const void *>(k_convolve_sums<5>)};
+  const void *fns[3] = {reinterpret_cast<const void *>(k_convolve_sums<3, 6>), reinterpret_cast<const void *>(k_convolve_sums<3, 5>),
+                        reinterpret_cast<const void *>(k_convolve_sums<4, 4>)};
   for (const void *f : fns)
   {
     const hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int) conv_lanes_lds(kLaneRows));
@@ -820,20 +820,18 @@ int convolve_batch(bioem_hip_ctx *h, const BatchBuf &bb, hipStream_t st, int nO,
   const char *fe = getenv("BIOEM_CONVOLVE_FUSED");
   if (fe ? atoi(fe) != 0 : h->nMaps <= 64)
   {
-    // chains on the lanes of the adding wave: as many orientations per block as 20 chains of two tiles fit in LDS
-    const int nCg = (nC + kConvCtfs - 1) / kConvCtfs;
-    const int nCb = std::min(nC, kConvCtfs);
-    const int R = std::max(3, std::min(5, kLaneRows / nCb)), rows = std::min(kLaneRows, R * nCb);
-    const dim3 grid(nCg, (nO + R - 1) / R);
-    if (R == 3)
-      hipLaunchKernelGGL(k_convolve_sums<3>, grid, dim3(kConvThreads), conv_lanes_lds(rows), st, bb.specRef, h->dCTF,
-                         h->dCtfParam, h->N, h->H, h->fast, h->N1, c0, nC, nO, rows, bb.conv, bb.params);
-    else if (R == 4)
-      hipLaunchKernelGGL(k_convolve_sums<4>, grid, dim3(kConvThreads), conv_lanes_lds(rows), st, bb.specRef, h->dCTF,
-                         h->dCtfParam, h->N, h->H, h->fast, h->N1, c0, nC, nO, rows, bb.conv, bb.params);
+    // chains on the lanes of the adding wave: 4 orientations x up to 4 CTFs, 3 x 5, or 3 x 6 per block (16, 15, 18
+    // products per producing thread and tile: more, and the producers -- ~25 vector instructions per product -- take
+    // longer than the 960 additions)
+    if (nC <= 4)
+      hipLaunchKernelGGL((k_convolve_sums<4, 4>), dim3(1, (nO + 3) / 4), dim3(kConvThreads), conv_lanes_lds(4 * nC), st,
+                         bb.specRef, h->dCTF, h->dCtfParam, h->N, h->H, h->fast, h->N1, c0, nC, nO, 4 * nC, bb.conv, bb.params);
+    else if (nC == 5)
+      hipLaunchKernelGGL((k_convolve_sums<3, 5>), dim3(1, (nO + 2) / 3), dim3(kConvThreads), conv_lanes_lds(15), st, bb.specRef,
+                         h->dCTF, h->dCtfParam, h->N, h->H, h->fast, h->N1, c0, nC, nO, 15, bb.conv, bb.params);
     else
-      hipLaunchKernelGGL(k_convolve_sums<5>, grid, dim3(kConvThreads), conv_lanes_lds(rows), st, bb.specRef, h->dCTF,
-                         h->dCtfParam, h->N, h->H, h->fast, h->N1, c0, nC, nO, rows, bb.conv, bb.params);
+      hipLaunchKernelGGL((k_convolve_sums<3, 6>), dim3((nC + 5) / 6, (nO + 2) / 3), dim3(kConvThreads), conv_lanes_lds(18), st,
+                         bb.specRef, h->dCTF, h->dCtfParam, h->N, h->H, h->fast, h->N1, c0, nC, nO, 18, bb.conv, bb.params);
     HIP_CHECK(h, hipGetLastError());
     return 0;
   }

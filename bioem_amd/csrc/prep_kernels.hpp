@@ -805,22 +805,24 @@ __device__ inline void lds_barrier()
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
-// A block takes R orientations, their chains (R x CTFs <= 20: two tiles of 960 terms each in 160 KiB of LDS) on the
-// LANES of the adding wave: its instruction stream is the one of a single orientation whatever R is -- one dependent
-// addition every ~12 cycles, 130...150 us per block at 224^2 -- and a producing thread forms the products of its position
-// for the R orientations, the CTF values read once.  Round 4, in the order measured (5 CTFs at 224^2, alone):
+// A block takes R orientations x up to NC CTFs, their chains (at most 20: two tiles of 960 terms each in 160 KiB of LDS)
+// on the LANES of the adding wave: its instruction stream is the one of a single orientation whatever R is, and a
+// producing thread forms the products of its position for the R orientations, the CTF values read once.  Round 4, in the order measured (5 CTFs at 224^2, alone):
 //   one orientation per block (round 3, tiles of 1 024 = a second round trip for 64 positions)  233 us per 256 orientations
 //   tiles of 960                                                                                  132
 //   two / three orientations as interleaved instructions of the adding wave: 200 / 265 us per block (130 for one)
 //   chains on lanes, tiles of 240 positions, 12 orientations per block: the producers' round trip (4.3 us) per 1 us of
 //     additions, 455 us per block; tiles of 960, 4 orientations: 152 us per block
 //   a second operand set fetched a tile ahead: 137 us for 3 orientations (128 registers hold no more)
+//   the adding wave's tile as straight-line code (below): 11.2 -> 8.9 cycles per term; the producers (~550 vector
+//     instructions per thread and tile at 20 products) are then the longer side of a 4 x 5 block, hence 3 x 6 / 4 x 4
+//     blocks with the operands fetched ahead
 // Timing-only builds of a one-orientation block on an otherwise idle chip: no stores 130 -> 127 us, no CTF loads 134,
 // no additions 73; 32, 64 or 128 terms in flight from LDS, or the adding wave alone on its SIMD, change nothing.
 constexpr int kLaneRows = 20;
 inline size_t conv_lanes_lds(int rows) { return sizeof(float) * 2 * rows * kConvStride; }
 
-template <int R>
+template <int R, int NC>
 __global__ __launch_bounds__(kConvThreads) void
 k_convolve_sums(const float2 *__restrict__ proj, const float2 *__restrict__ ctf, const float *__restrict__ ctfParam,
                  int N, int H, int fast, int N1, int c0, int nC, int nO, int rows, float2 *__restrict__ conv,
@@ -828,9 +830,9 @@ k_convolve_sums(const float2 *__restrict__ proj, const float2 *__restrict__ ctf,
 {
   extern __shared__ __align__(16) float terms[]; // [2][rows][kConvStride], rows >= R x CTFs of the block
   __shared__ float sC[kLaneRows];
-  const int ob0 = blockIdx.y * R, cg = blockIdx.x * kConvCtfs;
+  const int ob0 = blockIdx.y * R, cg = blockIdx.x * NC;
   const int nJ = min(R, nO - ob0);
-  const int nCb = min(kConvCtfs, nC - cg);
+  const int nCb = min(NC, nC - cg);
   const int M = N * H;
   const int even = ((N & 1) == 0);
   const int jend = even ? H - 1 : H;
@@ -841,7 +843,7 @@ k_convolve_sums(const float2 *__restrict__ proj, const float2 *__restrict__ ctf,
   // what a producing thread holds of one tile: the operands of its position and where the results go
   struct Operands
   {
-    float2 p[R], p1[R], kv[kConvCtfs], k1[kConvCtfs];
+    float2 p[R], p1[R], kv[NC], k1[NC];
     int ij, word; // (a spectrum has fewer than 2^31 elements: kMaxPixels)
     bool valid, twice, first, origin;
   };
@@ -872,7 +874,7 @@ k_convolve_sums(const float2 *__restrict__ proj, const float2 *__restrict__ ctf,
       L.p1[q] = P[partner];
     }
 #pragma unroll
-    for (int c = 0; c < kConvCtfs; c++)
+    for (int c = 0; c < NC; c++)
       if (c < nCb)
       {
         const float2 *Kc = K0 + (size_t) c * M;
@@ -889,7 +891,7 @@ k_convolve_sums(const float2 *__restrict__ proj, const float2 *__restrict__ ctf,
         break;
       float2 *O0 = conv + ((size_t) (ob0 + q) * nC + cg) * M;
 #pragma unroll
-      for (int c = 0; c < kConvCtfs; c++)
+      for (int c = 0; c < NC; c++)
         if (c < nCb)
         {
           float2 *O = O0 + (size_t) c * M;
@@ -922,40 +924,107 @@ k_convolve_sums(const float2 *__restrict__ proj, const float2 *__restrict__ ctf,
     {
       const float4 *q = reinterpret_cast<const float4 *>(terms + ((size_t) (t & 1) * rows + lane) * kConvStride);
       const int n4 = (min(kConvTile, M - t * kConvTile) + 3) >> 2; // the last tile ends with the spectrum
-#pragma unroll 4
-      for (int k = 0; k < n4; k++)
+      // one term after the other as the reference does (bioem.cpp:1896-1914).  The chain is this wave's instruction
+      // stream: a dependent v_add_f32 issues every 6.3 cycles (scripts/micro/dep_add.hip), and every other vector
+      // instruction between two of them costs its own four issue cycles on top -- with the address arithmetic of a
+      // rolled loop the chain ran at 11-12 cycles per term.  A full tile is therefore straight-line code: 240 reads at
+      // immediate offsets from one base register, a ring of eight 16-byte words in flight (28 additions between a read
+      // and its use; eight, not more: the LDS counter of s_waitcnt has four bits), nothing else.
+      constexpr int RING = 8, W4 = kConvTile / 4;
+      if (n4 == W4)
       {
-        // one term after the other as the reference does (bioem.cpp:1896-1914)
-        const float4 v = q[k];
-        ss += v.x;
-        ss += v.y;
-        ss += v.z;
-        ss += v.w;
+        float4 r[RING];
+#pragma unroll
+        for (int u = 0; u < RING; u++)
+          r[u] = q[u];
+#pragma unroll
+        for (int k = 0; k < W4; k++)
+        {
+          const float4 v = r[k % RING];
+          ss += v.x;
+          ss += v.y;
+          ss += v.z;
+          ss += v.w;
+          if (k + RING < W4)
+            r[k % RING] = q[k + RING];
+          __builtin_amdgcn_sched_barrier(0); // (left alone, the scheduler sinks the reads next to their use)
+        }
+      }
+      else
+      { // the last tile ends with the spectrum
+#pragma unroll 4
+        for (int k = 0; k < n4; k++)
+        {
+          const float4 v = q[k];
+          ss += v.x;
+          ss += v.y;
+          ss += v.z;
+          ss += v.w;
+        }
       }
     }
   };
-  // (fetching tile t + 2 before the products of tile t + 1 are formed -- a second set of operands -- fits 128 registers
-  // for three orientations only and buys 10 %: 137 against 152 us per block; four or five per block are worth more)
-  Operands A;
-  if (wave != 0)
+  // The producers fetch a tile ahead: the operands of tile t + 2 are requested before the products of tile t + 1 are
+  // formed (two operand sets: what 128 registers hold for 3 orientations x 6 CTFs or 4 x 4), so that a tile costs them
+  // their ~550 vector instructions and not a round trip to memory on top.  The two roles are two loops with the same
+  // number of barriers (in one loop the operand sets would stay live across the adding wave's ring of terms).
+#ifdef BIOEM_CONV_TIMING // timing-only build: the adding wave's cycles in additions / in total come back as sumC / sumsquareC
+  long long cyAdd = 0, cy0 = clock64();
+#endif
+  if (wave == 0)
   {
-    fetch(0, A);
-    produce(0, A);
+    __builtin_amdgcn_s_setprio(3); // the adding wave is the critical path: it issues ahead of the producers of its SIMD
+    lds_barrier();                 // tile 0 is there
+    for (int t = 0; t < nt; t++)
+    {
+#ifdef BIOEM_CONV_TIMING
+      asm volatile("" : "+v"(ss));
+      const long long c0 = clock64();
+#endif
+      add_tile(t);
+#ifdef BIOEM_CONV_TIMING
+      asm volatile("" : "+v"(ss));
+      cyAdd += clock64() - c0;
+#endif
+      lds_barrier();
+    }
   }
   else
-    __builtin_amdgcn_s_setprio(3); // the adding wave is the critical path: it issues ahead of the producers of its SIMD
-  lds_barrier();
-  for (int t = 0; t < nt; t++)
   {
-    if (wave == 0)
-      add_tile(t);
-    else if (t + 1 < nt)
-    {
-      fetch(t + 1, A);
-      produce(t + 1, A);
-    }
+    Operands A, B;
+    fetch(0, A);
+    if (1 < nt)
+      fetch(1, B);
+    produce(0, A);
     lds_barrier();
+    for (int t = 0; t < nt; t += 2)
+    {
+      // while the adding wave has tile t: tile t + 1 from B, tile t + 2 on its way into A
+      if (t + 1 < nt)
+      {
+        if (t + 2 < nt)
+          fetch(t + 2, A);
+        produce(t + 1, B);
+      }
+      lds_barrier();
+      if (t + 1 >= nt)
+        break;
+      if (t + 2 < nt)
+      {
+        if (t + 3 < nt)
+          fetch(t + 3, B);
+        produce(t + 2, A);
+      }
+      lds_barrier();
+    }
   }
+#ifdef BIOEM_CONV_TIMING
+  if (wave == 0 && lane < nJ * nCb)
+  {
+    sC[lane] = (float) cyAdd;
+    ss = (float) (clock64() - cy0) * (float) (N * N);
+  }
+#endif
   if (wave == 0 && lane < nJ * nCb)
   {
     const int o = lane / nCb, cl = lane - o * nCb;
