@@ -1216,7 +1216,7 @@ static int create_impl(bioem_hip_handle *out, int device, const bioem_hip_param_
     {
       fprintf(f, "%s\n", bioem_hip_kernel_signature(h));
       if (h->nyq)
-        fprintf(f, "k_nyquist_rows<%d>\n", (h->wide2 || h->fastm2) ? h->nyqWD : h->winD);
+        fprintf(f, "k_nyquist_rows<%d, %d>\n", (h->wide2 || h->fastm2) ? h->nyqWD : h->winD, h->nMaps <= 64 ? 4 : 1);
       fclose(f);
     }
   return 0;

@@ -38,3 +38,20 @@ def test_kernel_instantiation_against_oracle(shape):
         assert_workload_matches(got, want, const, sel)
     finally:
         W.engine.close()
+
+
+@pytest.mark.parametrize("d", [5, 10, 13, 15, 20, 30, 40])
+@pytest.mark.parametrize("nP", [3, 66])
+def test_nyquist_column_kernel_against_oracle(d, nP):
+    """k_nyquist_rows<WD, Q> (the Nyquist column of 128^2 / 256^2 by direct summation, compare_fast.hpp): every window
+    depth the comparison kernels ask for, with four waves per 64 pairs (64 particles or fewer) and with one thread per
+    pair (more)."""
+    from bioem_amd.synthetic import Workload
+    W = Workload(N=128, nP=nP, nOrient=2, nEnv=2, maxD=d, npts=150)
+    try:
+        sel = [0, 1, nP - 1]
+        want, const = oracle_on_workload(W, sel, 2, 1)
+        _, got = run_workload(W, 0, 2)
+        assert_workload_matches(got, want, const, sel)
+    finally:
+        W.engine.close()
