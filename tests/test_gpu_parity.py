@@ -861,6 +861,40 @@ def assert_workload_matches(got, want, const, sel):
                (want[i]["orient"], want[i]["conv"], want[i]["cent_x"], want[i]["cent_y"])
 
 
+PREP_SHAPES = {
+    # name: (N, orientations, envelopes, defoci) -- what the preparation kernels see: CTFs per block of k_convolve_sums
+    # (4 x <= 4, 3 x 5, 3 x 6, several groups of six), orientation counts that do not fill the last block, an odd size
+    "ctf1": (64, 5, 1, 1), "ctf3": (64, 7, 3, 1), "ctf4": (96, 6, 4, 1), "ctf5": (64, 4, 5, 1), "ctf6": (64, 5, 6, 1),
+    "ctf7_two_groups": (64, 4, 7, 1), "ctf13_three_groups": (80, 3, 13, 1), "ctf10_defocus": (64, 4, 5, 2),
+    "odd75": (75, 5, 5, 1), "one_orientation": (64, 1, 5, 1),
+}
+
+
+@pytest.mark.parametrize("name", sorted(PREP_SHAPES) + ["stretching_quaternions", "model_beyond_the_box"])
+def test_preparation_kernels_against_oracle(name):
+    """Projection (k_project_box; the band kernel where the model leaves the box or the quaternions are not of unit
+    length), the boxed r2c and k_convolve_sums<R, NC> in every block shape, through the whole path against the oracle."""
+    from bioem_amd.synthetic import Workload
+    N, nO, nEnv, nDef = PREP_SHAPES.get(name, (128 if name == "model_beyond_the_box" else 64, 3, 2, 1))
+    W = Workload(N=N, nP=3, nOrient=nO, nEnv=nEnv, nDefocus=nDef, npts=150, render=False)
+    try:
+        E = W.engine
+        if name == "stretching_quaternions":     # the reference's matrix is no rotation then (bioem.cpp:1632-1646)
+            W.angles = (W.angles * np.float32(1.07)).astype(np.float32)
+            E.upload_orientations(W.angles, True)
+        if name == "model_beyond_the_box":       # three times the extent: the box would be the whole map
+            W.points["pos"] *= np.float32(3.0)
+            E.upload_model(W.points, W.NormDen, W.px)
+        W.maps = W.render_particles(0.05)
+        E.upload_particle_maps(W.maps)
+        sel = [0, 1, 2]
+        want, const = oracle_on_workload(W, sel, nO, 1)
+        _, got = run_workload(W, 0, nO)
+        assert_workload_matches(got, want, const, sel)
+    finally:
+        W.engine.close()
+
+
 def test_full_size_slice_against_oracle(full_workload):
     """224^2, all 5 CTFs, 6 orientations x 8 particles of the benchmark workload through the CPU oracle."""
     W = full_workload
