@@ -784,14 +784,13 @@ __global__ __launch_bounds__(64) void k_parseval_ordered(const float *__restrict
 
 // ------------------------------------------------------------------------------------------------
 // k_convolve_sums: the two kernels above in one -- no Parseval terms through global memory.
-// One block per (R orientations, group of up to kConvCtfs CTFs).  Waves 1..15 form the products of a tile of kConvTile
+// One block per (R orientations, group of up to NC CTFs).  Waves 1..15 form the products of a tile of kConvTile
 // consecutive positions of the reference's summation order for every CTF of the group (the projection element is read
 // once), store the spectra and leave the terms in LDS; wave 0 adds the previous tile meanwhile, one lane per
 // (orientation, CTF), one term after the other as the reference does.  In the comparison layout a 16-byte word holds the rows kx and kx + N1:
 // it is written when the first of them comes by (its partner's product is formed there for the store, and once more
 // when its own position in the order is reached: same operands, same bits).
 // ------------------------------------------------------------------------------------------------
-constexpr int kConvCtfs = 6;
 constexpr int kConvThreads = 1024; // one adding wave, fifteen producing waves
 // a tile is one position per producing thread: its loads (the projection element, its partner row, the CTFs' values)
 // go out together and a tile costs the producers one round trip to memory.  (Round 3 had tiles of 1 024: a second,
@@ -819,7 +818,7 @@ __device__ inline void lds_barrier()
 //     blocks with the operands fetched ahead
 // Timing-only builds of a one-orientation block on an otherwise idle chip: no stores 130 -> 127 us, no CTF loads 134,
 // no additions 73; 32, 64 or 128 terms in flight from LDS, or the adding wave alone on its SIMD, change nothing.
-constexpr int kLaneRows = 20;
+constexpr int kLaneRows = 20; // chains per block at most
 inline size_t conv_lanes_lds(int rows) { return sizeof(float) * 2 * rows * kConvStride; }
 
 template <int R, int NC>
