@@ -134,7 +134,7 @@ struct bioem_hip_ctx
   bioem_hip_model_point *dPts = nullptr;
   double *dStamp = nullptr; // sphere footprints of the model (k_project_stamps), (2 iradMax + 1)^2 doubles per point
   double modelRadius = 0.;  // max |point| of the model, Angstrom (k_project_box)
-  bool anglesKeepLength = true; // every uploaded quaternion is of unit length (Euler angles always are rotations)
+  double quatNormDev = 0.;  // max | |q|^2 - 1 | over the uploaded quaternions (0 for Euler angles: always rotations)
   int nPts = 0;
   float NormDen = 0, pixelSize = 0;
   int shiftX = 0, shiftY = 0;
@@ -681,9 +681,12 @@ int project_batch(bioem_hip_ctx *h, const BatchBuf &bb, hipStream_t st, int o0, 
   const int boxLo = std::max(0, (int) std::floor(N / 2.0 + 0.5 - reach) - 1 - h->iradMax - std::max(0, std::max(h->shiftX, h->shiftY)));
   const int boxHi = std::min(N - 1, (int) std::floor(N / 2.0 + 0.5 + reach) + 1 + h->iradMax - std::min(0, std::min(h->shiftX, h->shiftY)));
   const int boxSide = boxHi - boxLo + 1;
-  // (orientations that stretch the model -- quaternions that are not of unit length -- take the band kernel)
+  // (orientations that stretch the model -- quaternions that are not of unit length -- take the band kernel: the box
+  // has one pixel of margin; the matrix entries of a quaternion with |q|^2 = 1 + e are off by at most ~3 e, and half a
+  // pixel is granted to that)
+  const bool keepLength = h->quatNormDev * 4.0 * std::max(1.0, reach) < 0.5;
   if (h->dStamp && boxSide >= 1 && (size_t) boxSide * boxSide * sizeof(double) <= 52 * 1024 && N < 32768 &&
-      h->anglesKeepLength && !getenv("BIOEM_PROJECT_BANDS") && !getenv("BIOEM_PROJECT_GLOBAL_ATOMICS"))
+      keepLength && !getenv("BIOEM_PROJECT_BANDS") && !getenv("BIOEM_PROJECT_GLOBAL_ATOMICS"))
   {
     // with the fast r2c behind it the kernel stores the box alone and the transform skips everything outside it
     const int compact = r2c_use_fft(N) && !getenv("BIOEM_PROJECT_FULL_MAP");
@@ -1386,20 +1389,17 @@ int bioem_hip_upload_orientations(bioem_hip_handle h, const float *angles4, int 
   h->nAnglesUp = n;
   h->isQuat = isQuat;
   // k_project_box relies on the rotated model staying inside its box: the reference's quaternion matrix
-  // (bioem.cpp:1632-1646) is a rotation only for unit quaternions; a list that stretches the model by more than a
-  // fraction of a pixel takes the band kernel instead
-  h->anglesKeepLength = true;
+  // (bioem.cpp:1632-1646) is a rotation only for unit quaternions; project_batch holds the list's largest deviation
+  // against the model's extent and sends a list that stretches the model by a fraction of a pixel to the band kernel
+  h->quatNormDev = 0.;
   if (isQuat)
-  {
-    const double reach = h->pixelSize > 0.f ? std::max(1.0, h->modelRadius / (double) h->pixelSize) : 1e4;
-    for (int k = 0; k < n && h->anglesKeepLength; k++)
+    for (int k = 0; k < n; k++)
     {
       const float *q = angles4 + 4 * (size_t) k;
       const double n2 = (double) q[0] * q[0] + (double) q[1] * q[1] + (double) q[2] * q[2] + (double) q[3] * q[3];
-      if (!(std::fabs(n2 - 1.0) * 2.0 * reach < 0.25))
-        h->anglesKeepLength = false;
+      const double dev = std::fabs(n2 - 1.0);
+      h->quatNormDev = dev == dev ? std::max(h->quatNormDev, dev) : 1e30; // (a NaN never passes)
     }
-  }
   return 0;
 }
 
