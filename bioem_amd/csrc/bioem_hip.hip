@@ -1365,9 +1365,9 @@ int bioem_hip_upload_model(bioem_hip_handle h, const bioem_hip_model_point *pts,
   if (h->dStamp)
     hipFree(h->dStamp);
   h->dStamp = nullptr;
-  if (h->iradMax <= 16 && nPts > 0)
+  const size_t cells = (size_t) nPts * (2 * h->iradMax + 1) * (2 * h->iradMax + 1);
+  if (h->iradMax <= 16 && nPts > 0 && cells <= ((size_t) 1 << 27)) // at most 1 GiB of footprints, else k_project
   {
-    const size_t cells = (size_t) nPts * (2 * h->iradMax + 1) * (2 * h->iradMax + 1);
     HIP_CHECK(h, hipMalloc(&h->dStamp, sizeof(double) * cells));
     hipLaunchKernelGGL(k_project_stamps, dim3((unsigned) ((cells + 255) / 256)), dim3(256), 0, h->stream, h->dPts, nPts,
                        h->iradMax, pixelSize, h->dStamp);
