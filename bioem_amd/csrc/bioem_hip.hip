@@ -10,7 +10,7 @@
 //                          rows in LDS) for models beyond the box, k_project (global double atomics) beyond 426 pixels
 //                        k_convolve       proj * conj(CTF) -> conv spectra in the comparison layout, sumC, Parseval terms
 //                        k_parseval_ordered  sumsquareC: the reference's sequential float sum, four chains per wave
-//                        k_convolve_sums  the two in one kernel (64 particles or fewer), 3...5 orientations per block
+//                        k_convolve_sums  the two in one kernel (256 particles or fewer), 3...4 orientations per block
 //                        k_dft_rows/cols  r2c by exact DFT on the vector units (images beyond 304 pixels)
 //   r2c_fft.hpp          k_r2c_fft        r2c of the projections and particle maps (kernels_r2c.hip): one Cooley-Tukey split,
 //                          register FFTs of 2...20 points in double; the rows of the projection's box only
@@ -403,8 +403,11 @@ int launch_compare_fold(bioem_hip_ctx *h, const BatchBuf &bb, int nOC, int orien
   a.gs = h->gs;
   a.ndx = a.ndy = h->nd;
   a.pchunk = h->pchunk > 0 ? std::min(h->pchunk, h->nMaps) : h->nMaps;
+  if (a.pchunk >= 8) // a multiple of 8: a particle then stays on one XCD (65 particles: chunks of 64 + 1, 43.6 -> 45.3 M/s)
+    a.pchunk &= ~7;
   const int ocGroups = (nOC + 3) / 4;
   // few particles: whole groups per XCD (fast_block_pair); the grid is padded to a multiple of 8 groups
+  // (measured for 65...200 particles as well: 1-3 % slower than the chunk order there)
   const bool groupPerXcd = h->nMaps <= 64 && h->fast && !h->wide2 && !getenv("BIOEM_NO_GROUP_XCD");
   if (groupPerXcd)
     a.pchunk = -1;
@@ -816,12 +819,12 @@ int compat_flush(bioem_hip_ctx *h)
 // conv spectra of CTFs [c0, c0 + nC) of the nO projected orientations, row ob * nC + (c - c0)
 int convolve_batch(bioem_hip_ctx *h, const BatchBuf &bb, hipStream_t st, int nO, int c0, int nC)
 {
-  // few particles: the preparation is the longer half of the pipeline and the fused kernel shortens it (20 particles:
-  // 9.3 -> 8.4 ms per pass); many particles: it hides behind the comparison either way, and the one-wave blocks of
-  // k_parseval_ordered take less from the comparison kernel than the 16-wave blocks of k_convolve_sums (1 000
-  // particles: 53.0 against 52.0 M comparisons/s)
+  // few particles: the preparation is the longer half of the pipeline and the fused kernel shortens it; many particles:
+  // it hides behind the comparison either way, and the one-wave blocks of k_parseval_ordered take less from the
+  // comparison kernel than the 16-wave blocks of k_convolve_sums (round 4, the fused kernel with 3-4 orientations per
+  // block: 65...200 particles +1...3 %, 400 particles equal, 1 000 particles 52.5 against 53.4 M comparisons/s)
   const char *fe = getenv("BIOEM_CONVOLVE_FUSED");
-  if (fe ? atoi(fe) != 0 : h->nMaps <= 64)
+  if (fe ? atoi(fe) != 0 : h->nMaps <= 256)
   {
     // chains on the lanes of the adding wave: 4 orientations x up to 4 CTFs, 3 x 5, or 3 x 6 per block (16, 15, 18
     // products per producing thread and tile: more, and the producers -- ~25 vector instructions per product -- take
