@@ -359,9 +359,32 @@ bool plan_window_kernel(KernelPlan &P, int N, int H, int winD, bool untiled)
     if (nyq)
       lens.push_back(32);
     else
+    {
       fft_lengths(N, 32, P.gs == 1 && !getenv("BIOEM_POW2_FFT"), lens);
+      // up to 256 pixels the longest length is not the fastest (round 4, sweep of every length in the table over 64...240
+      // pixels, 1 000 particles): 21-row windows 16 > 12 > 20 > 18 > 10 > 32 > 30 > 8 (224^2: 51.0 / 50.0 / 47.5 M/s
+      // with 16 / 32 / 8 points, 180^2: 61.0 with 12 against 59.5 with 30), 11-row windows 8 first up to 160 pixels
+      // (64^2: 271 / 259 / 228 M/s with 8 / 16 / 32), 16 first above (224^2: 57.1 / 55.8 / 55.7); from 288 pixels on
+      // 32 and 16 points are level and the order stays
+      if (N <= 256 && !getenv("BIOEM_LONGEST_FFT"))
+      {
+        static const int pref21[] = {16, 12, 20, 18, 10, 32, 30, 8, 6, 4, 2};
+        static const int pref11s[] = {8, 16, 12, 10, 18, 20, 32, 30, 6, 4, 2};
+        static const int pref11l[] = {16, 12, 18, 10, 8, 20, 32, 30, 6, 4, 2};
+        const int *pref = winD == 5 ? (N <= 160 ? pref11s : pref11l) : pref21;
+        auto rank = [&](int r) {
+          for (int k = 0; k < 11; k++)
+            if (pref[k] == r)
+              return k;
+          return 11;
+        };
+        std::stable_sort(lens.begin(), lens.end(), [&](int a, int b) { return rank(a) < rank(b); });
+      }
+    }
     for (int R : lens)
     {
+      if (getenv("BIOEM_FAST_R") && R != atoi(getenv("BIOEM_FAST_R"))) // timing experiments: another register-FFT length
+        continue;
       int wd = winD;
       // 11-row windows: with four column blocks and a length <= 16 (or 40+ column steps) the 21-row template is the
       // faster one (+-5 px: 432^2 11.0 -> 13.0 M/s, 360^2 16.7 -> 19.2, 400^2 13.5 -> 14.7)

@@ -13,8 +13,8 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
-SIZES = [8, 10, 16, 24, 32, 34, 36, 40, 42, 44, 48, 50, 56, 60, 64, 72, 80, 84, 88, 90, 96, 100, 112, 120, 128, 144, 150, 160,
-         176, 180, 192, 200, 208, 210, 224, 240, 248, 250, 256, 264, 272, 280, 288, 290, 300, 320, 360, 380, 384, 400, 432,
+SIZES = [8, 10, 16, 24, 32, 34, 36, 40, 42, 44, 48, 50, 56, 60, 64, 72, 80, 84, 88, 90, 96, 100, 112, 120, 126, 128, 144, 150, 160,
+         176, 180, 192, 198, 200, 208, 210, 224, 240, 248, 250, 256, 264, 272, 280, 288, 290, 300, 320, 360, 380, 384, 400, 432,
          448, 512, 600, 9, 33, 35, 51, 75, 99, 125, 127, 129, 135, 225]
 WINDOWS = [0, 2, 4, 5, 7, 9, 10, 11, 12, 13, 14, 15, 16, 18, 20, 21, 22, 24, 25, 26, 27, 30, 33, 35, 37, 38, 40, 41, 42, 43,
            44, 45, 47, 56, 60, 62, 64, 78, 80, 88]

@@ -1,5 +1,5 @@
 """Kernel selection (bioem_amd/csrc/kernel_select.hpp) without a GPU: bioem_hip_plan is a pure function of the image size
-and the displacement set.  The committed snapshot (tests/golden/selection_snapshot.txt.gz: 16 856 shapes -- 65 image
+and the displacement set.  The committed snapshot (tests/golden/selection_snapshot.txt.gz: 17 528 shapes -- 67 image
 sizes x 40 window half widths x grid spacings 1..5 x ALGO 1/2, written by scripts/selection_snapshot.py --plan) pins
 what every shape runs; a change of the table or the rules shows up here as a diff, on purpose."""
 import ctypes as C
@@ -58,7 +58,9 @@ def test_every_table_entry_is_selected_by_some_shape_of_the_snapshot():
 def test_headline_shapes():
     import bioem_amd.engine as eng
     L = eng.load_library()
-    assert plan(L, 224, 10, 1, 1) == "k_compare_fast<10, 32, false, 1>"            # BASELINE config 2 / 3
+    assert plan(L, 224, 10, 1, 1) == "k_compare_fast<10, 16, false, 1>"            # BASELINE config 2 / 3
+    assert plan(L, 288, 10, 1, 1) == "k_compare_fast<10, 32, false, 1>"            # beyond 256 pixels: the longest length
+    assert plan(L, 64, 5, 1, 1) == "k_compare_fast<5, 8, false, 1>"                # 11 rows, small image: 8 points
     assert plan(L, 128, 10, 1, 1) == "k_compare_fast<10, 32, true, 1>"             # config 1 / 4 (Nyquist split)
     assert plan(L, 256, 10, 1, 1) == "k_compare_fast<10, 32, true, 1>"             # config 5
     assert plan(L, 224, 13, 1, 1) == "k_compare_fastm<13, 16, false, 1>"           # 27 rows: matrix-core window pass
