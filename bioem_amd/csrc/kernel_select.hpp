@@ -20,6 +20,8 @@
 //   BIOEM_NO_ROWS_KERNEL  odd sizes on k_compare_generic
 //   BIOEM_NO_ODD_FFT      odd sizes on k_compare_rows (direct column sums) even where an odd register FFT divides N
 //   BIOEM_POW2_FFT        power-of-two register FFTs only
+//   BIOEM_LONGEST_FFT     k_compare_fast with the longest register FFT at every size (round 3's rule)
+//   BIOEM_FAST_R=<len>    k_compare_fast with this register-FFT length only (sweeps)
 //   BIOEM_KEEP_WD5        11-row windows keep the 11-row template at every size
 // (run-time knobs outside the selection: BIOEM_PCHUNK, BIOEM_BATCH_ORIENTATIONS, BIOEM_FIXED_BATCH, BIOEM_NO_GROUP_XCD,
 //  BIOEM_COMPAT_RING, BIOEM_SERIAL_FOLD, BIOEM_SIGNATURE_LOG, BIOEM_HIP_LIBRARY (Python loader))
