@@ -359,10 +359,17 @@ bool plan_window_kernel(KernelPlan &P, int N, int H, int winD, bool untiled)
     }
     std::vector<int> lens;
     if (nyq)
+    { // 128^2, 256^2, ...: 32 points, and the shorter lengths that the sweep below found faster (128^2 +-5 px: 155 -> 173
+      // M/s with 8 points; 128^2 / 256^2 +-10 px: +1.4 / +1.9 % with 16; 256^2 +-5 px: 16 level, 8 slower)
       lens.push_back(32);
+      if (winD != 5)
+        lens.push_back(16);
+      else if (N <= 160)
+        lens.push_back(8);
+    }
     else
-    {
       fft_lengths(N, 32, P.gs == 1 && !getenv("BIOEM_POW2_FFT"), lens);
+    {
       // up to 256 pixels the longest length is not the fastest (round 4, sweep of every length in the table over 64...240
       // pixels, 1 000 particles): 21-row windows 16 > 12 > 20 > 18 > 10 > 32 > 30 > 8 (224^2: 51.0 / 50.0 / 47.5 M/s
       // with 16 / 32 / 8 points, 180^2: 61.0 with 12 against 59.5 with 30), 11-row windows 8 first up to 160 pixels

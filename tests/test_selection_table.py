@@ -61,8 +61,10 @@ def test_headline_shapes():
     assert plan(L, 224, 10, 1, 1) == "k_compare_fast<10, 16, false, 1>"            # BASELINE config 2 / 3
     assert plan(L, 288, 10, 1, 1) == "k_compare_fast<10, 32, false, 1>"            # beyond 256 pixels: the longest length
     assert plan(L, 64, 5, 1, 1) == "k_compare_fast<5, 8, false, 1>"                # 11 rows, small image: 8 points
-    assert plan(L, 128, 10, 1, 1) == "k_compare_fast<10, 32, true, 1>"             # config 1 / 4 (Nyquist split)
-    assert plan(L, 256, 10, 1, 1) == "k_compare_fast<10, 32, true, 1>"             # config 5
+    assert plan(L, 128, 10, 1, 1) == "k_compare_fast<10, 16, true, 1>"             # config 1 / 4 (Nyquist split)
+    assert plan(L, 256, 10, 1, 1) == "k_compare_fast<10, 16, true, 1>"             # config 5
+    assert plan(L, 384, 10, 1, 1) == "k_compare_fast<10, 32, true, 1>"
+    assert plan(L, 128, 5, 1, 1) == "k_compare_fast<5, 8, true, 1>"
     assert plan(L, 224, 13, 1, 1) == "k_compare_fastm<13, 16, false, 1>"           # 27 rows: matrix-core window pass
     assert plan(L, 224, 20, 1, 1) == "k_compare_fastm2<16, false, 1>"              # 41 rows: rows split over the half-waves
     assert plan(L, 128, 16, 1, 2) == "k_compare_fastm2<16, true, 1>"
