@@ -343,6 +343,9 @@ bool plan_window_kernel(KernelPlan &P, int N, int H, int winD, bool untiled)
       else
         fft_lengths(N, 16, P.gs == 1 && !getenv("BIOEM_POW2_FFT"), lens);
       for (int R : lens)
+      {
+        if (getenv("BIOEM_FAST_R") && R != atoi(getenv("BIOEM_FAST_R")))
+          continue;
         if (const fast_kernel_t fn = find_kernel(KF_FASTM, winD, R, nyq, P.gs))
         {
           P.family = KF_FASTM;
@@ -355,6 +358,7 @@ bool plan_window_kernel(KernelPlan &P, int N, int H, int winD, bool untiled)
           P.ldsBytes = fastm_lds_bytes(N);
           return true;
         }
+      }
       return false;
     }
     std::vector<int> lens;
