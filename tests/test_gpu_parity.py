@@ -895,6 +895,22 @@ def test_preparation_kernels_against_oracle(name):
         W.engine.close()
 
 
+@pytest.mark.parametrize("px", [0.9, 0.5, 3.6])
+def test_projection_footprints_of_other_widths_against_oracle(px):
+    """k_project_stamps / k_project_box with sphere footprints of 9 and 15 pixels (pixel sizes 0.9 and 0.5 A for radii of
+    2.25...3.4 A: the footprint column is fetched in two and three groups of five entries) and with every sphere a
+    single pixel (3.6 A: radius <= pixel size, bioem.cpp:1700-1712), through the whole path against the oracle."""
+    from bioem_amd.synthetic import Workload
+    W = Workload(N=96, nP=3, nOrient=5, nEnv=3, px=px, npts=150)
+    try:
+        sel = [0, 1, 2]
+        want, const = oracle_on_workload(W, sel, 5, 1)
+        _, got = run_workload(W, 0, 5)
+        assert_workload_matches(got, want, const, sel)
+    finally:
+        W.engine.close()
+
+
 def test_full_size_slice_against_oracle(full_workload):
     """224^2, all 5 CTFs, 6 orientations x 8 particles of the benchmark workload through the CPU oracle."""
     W = full_workload
