@@ -31,6 +31,8 @@ struct CompareArgs
   // k_compare_wide2: row stride of the LDS T block (float2 units); window half width of the k_nyquist_rows
   // instantiation that filled tnyq (its rows run -nyqWD..nyqWD)
   int ts, nyqWD;
+  // k_compare_fast: the last column block holds at most 32 columns and its half-waves share them (compare_fast.hpp)
+  int split;
   PD pd;
 };
 

@@ -1110,6 +1110,31 @@ def test_image_sizes_against_oracle(N, maxD, grid, fast, algo):
         W.engine.close()
 
 
+# k_compare_fast with a last column block of at most 32 columns: its half-waves share the columns, the low half the first
+# ceil(N1 / 2) k1 steps, the high half the rest (compare_fast.hpp).  One block only (60), two (144...190), three (288,
+# 300), even and odd N1 (160 = 10 x 16, 144 = 9 x 16, 150 = 15 x 10, 190 = 19 x 10), 11- and 21-row windows, a coarse grid
+@pytest.mark.parametrize("N,maxD,grid", [(60, 10, 1), (144, 10, 1), (150, 5, 1), (160, 10, 1), (160, 5, 1), (176, 20, 2),
+                                         (190, 10, 1), (288, 10, 1), (300, 5, 1), (138, 9, 1)])
+@pytest.mark.parametrize("algo", [1, 2])
+def test_split_last_column_block_against_oracle(N, maxD, grid, algo, monkeypatch):
+    from bioem_amd.synthetic import Workload
+    nP, nO = 5, 6
+    W = Workload(N=N, nP=nP, nOrient=nO, nEnv=2, maxD=maxD, grid=grid, algo=algo, npts=300)
+    try:
+        assert W.engine.kernel_signature.startswith("k_compare_fast<")
+        sel = list(range(nP))
+        want, const = oracle_on_workload(W, sel, nO, algo)
+        _, got = run_workload(W, 0, nO)
+        assert_workload_matches(got, want, const, sel)
+        # and the unsplit pass of the same kernel (BIOEM_NO_SPLIT_LAST is read at every launch): the same arg-max tuples
+        monkeypatch.setenv("BIOEM_NO_SPLIT_LAST", "1")
+        _, plain = run_workload(W, 0, nO)
+        assert_workload_matches(plain, want, const, sel)
+        assert np.array_equal(got["orient"], plain["orient"]) and np.array_equal(got["cent_x"], plain["cent_x"])
+    finally:
+        W.engine.close()
+
+
 # k_compare_wide2 (shared column transforms + row FFT) is picked from three 21-row tiles per axis on; forced here for
 # every register-FFT length, one and two column blocks, the Nyquist split, row strides 1..3, odd and even row counts
 # per wave, windows from +-16 to +-41 px
