@@ -403,9 +403,9 @@ int launch_compare_fold(bioem_hip_ctx *h, const BatchBuf &bb, int nOC, int orien
   a.gs = h->gs;
   a.ndx = a.ndy = h->nd;
   {
-    // k_compare_fast: a last column block of at most 32 columns is shared by the half-waves (compare_fast.hpp)
+    // k_compare_fast / k_compare_fastm: a last column block of at most 32 columns is shared by the half-waves
     const int nblkF = (h->H + 63) / 64, rem = h->H - (nblkF - 1) * 64;
-    a.split = h->fast && !h->fastm && !h->fastm2 && !h->wide2 && !h->rowsK && !h->nyq && rem <= 32 && h->N1 >= 2 &&
+    a.split = h->fast && !h->fastm2 && !h->wide2 && !h->rowsK && !h->nyq && rem <= 32 && h->N1 >= 2 &&
               !getenv("BIOEM_NO_SPLIT_LAST");
   }
   a.pchunk = h->pchunk > 0 ? std::min(h->pchunk, h->nMaps) : h->nMaps;

@@ -102,11 +102,22 @@ __global__ __launch_bounds__(256, 3) void k_compare_fastm(const CompareArgs a)
   floatx16 Dfin;
 
   const int nblk = NYQ ? (H - 1) / 64 : (H + 63) / 64;
-  const int ttotal = R2 * N1;
   const unsigned rowbytes = (unsigned) H * 16u;
+  // split last block (a.split, as in k_compare_fast: at most 32 columns, shared by the half-waves -- the low half the k1
+  // steps 0 .. sHalf - 1, the high half the rest, its sums turned by w^(dx sHalf) and added after the loop)
+  // (the 31-row kernels with 10- and 8-point FFTs have no registers left for it: they keep the whole pass)
+  constexpr bool SPLIT_OK = !NYQ && !(WD == 15 && R <= 10);
+  const int sHalf = (N1 + 1) >> 1;
+  const int hsel = lane >> 5;
+  const unsigned halfoff = (unsigned) (hsel * sHalf * R2) * rowbytes;
+  auto lane_offset = [&](int b) -> unsigned {
+    const bool sp = SPLIT_OK && a.split && b == nblk - 1;
+    const int kyb = b * 64 + (sp ? (lane & 31) : lane);
+    return (unsigned) (kyb < H ? kyb : H - 1) * 16u + (sp ? halfoff : 0u);
+  };
   u32x4 rf[RD], rc[RD];
   {
-    const unsigned lo0 = (unsigned) (lane < H ? lane : H - 1) * 16u;
+    const unsigned lo0 = lane_offset(0);
 #pragma unroll
     for (int t = 0; t < RD; t++)
     {
@@ -116,11 +127,12 @@ __global__ __launch_bounds__(256, 3) void k_compare_fastm(const CompareArgs a)
   }
   for (int blk = 0; blk < nblk; blk++)
   {
-    const int ky = blk * 64 + lane;
-    const int kyc = ky < H ? ky : H - 1;
-    const unsigned laneoff = (unsigned) kyc * 16u;
-    const int kyn = ky + 64 < H ? ky + 64 : H - 1;
-    const unsigned laneoff_next = (unsigned) kyn * 16u;
+    const bool split = SPLIT_OK && a.split && blk == nblk - 1;
+    const int n1 = split ? sHalf : N1;
+    const int ttotal = R2 * n1;
+    const int ky = blk * 64 + (split ? (lane & 31) : lane);
+    const unsigned laneoff = lane_offset(blk);
+    const unsigned laneoff_next = lane_offset(min(blk + 1, nblk - 1));
     const bool has_next = blk + 1 < nblk;
     float Tr[NW], Ti[NW];
 #pragma unroll
@@ -130,7 +142,7 @@ __global__ __launch_bounds__(256, 3) void k_compare_fastm(const CompareArgs a)
       Ti[d] = 0.f;
     }
     if (ky < H)
-    for (int k1 = 0; k1 < N1; k1++)
+    for (int k1 = 0; k1 < n1; k1++)
     {
       float xr[R], xi[R];
       const const_float2_ptr twk = as_constant(a.twk) + (size_t) k1 * NW;
@@ -187,11 +199,25 @@ __global__ __launch_bounds__(256, 3) void k_compare_fastm(const CompareArgs a)
         }
       }
     }
+    if (split)
+    {
+      const const_float2_ptr ws = as_constant(a.twk) + (size_t) sHalf * NW; // w^(dx sHalf), the table's row sHalf
+#pragma unroll
+      for (int d = 0; d < NW; d++)
+      {
+        const float wx = hsel ? ws[d].x : 1.f, wy = hsel ? ws[d].y : 0.f;
+        const float tr = fmaf(-Ti[d], wy, Tr[d] * wx), ti = fmaf(Ti[d], wx, Tr[d] * wy);
+        const u32x2 sr = __builtin_amdgcn_permlane32_swap(__float_as_uint(tr), __float_as_uint(tr), false, false);
+        const u32x2 si = __builtin_amdgcn_permlane32_swap(__float_as_uint(ti), __float_as_uint(ti), false, false);
+        Tr[d] = __uint_as_float(sr.x) + __uint_as_float(sr.y); // low half + high half, in every lane
+        Ti[d] = __uint_as_float(si.x) + __uint_as_float(si.y);
+      }
+    }
     // FFTW c2r convention: columns 0 and N/2 enter once (real part only after the ky pass), others twice
     float wgt = 2.f;
     if (ky == 0 || (((N & 1) == 0) && ky == N / 2))
       wgt = 1.f;
-    if (ky >= H)
+    if (ky >= H || (split && hsel))
       wgt = 0.f;
     floatx16 D;
     if (blk == 0)

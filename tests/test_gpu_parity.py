@@ -1114,14 +1114,16 @@ def test_image_sizes_against_oracle(N, maxD, grid, fast, algo):
 # ceil(N1 / 2) k1 steps, the high half the rest (compare_fast.hpp).  One block only (60), two (144...190), three (288,
 # 300), even and odd N1 (160 = 10 x 16, 144 = 9 x 16, 150 = 15 x 10, 190 = 19 x 10), 11- and 21-row windows, a coarse grid
 @pytest.mark.parametrize("N,maxD,grid", [(60, 10, 1), (144, 10, 1), (150, 5, 1), (160, 10, 1), (160, 5, 1), (176, 20, 2),
-                                         (190, 10, 1), (288, 10, 1), (300, 5, 1), (138, 9, 1)])
+                                         (190, 10, 1), (288, 10, 1), (300, 5, 1), (138, 9, 1),
+                                         # ... and of k_compare_fastm (27 / 31 rows)
+                                         (160, 13, 1), (144, 15, 1), (150, 13, 1), (176, 26, 2), (288, 15, 1), (60, 13, 1)])
 @pytest.mark.parametrize("algo", [1, 2])
 def test_split_last_column_block_against_oracle(N, maxD, grid, algo, monkeypatch):
     from bioem_amd.synthetic import Workload
     nP, nO = 5, 6
     W = Workload(N=N, nP=nP, nOrient=nO, nEnv=2, maxD=maxD, grid=grid, algo=algo, npts=300)
     try:
-        assert W.engine.kernel_signature.startswith("k_compare_fast<")
+        assert W.engine.kernel_signature.startswith(("k_compare_fast<", "k_compare_fastm<"))
         sel = list(range(nP))
         want, const = oracle_on_workload(W, sel, nO, algo)
         _, got = run_workload(W, 0, nO)
