@@ -404,9 +404,12 @@ int launch_compare_fold(bioem_hip_ctx *h, const BatchBuf &bb, int nOC, int orien
   a.ndx = a.ndy = h->nd;
   {
     // k_compare_fast / k_compare_fastm: a last column block of at most 32 columns is shared by the half-waves
-    const int nblkF = (h->H + 63) / 64, rem = h->H - (nblkF - 1) * 64;
-    a.split = h->fast && !h->fastm2 && !h->wide2 && !h->rowsK && !h->nyq && rem <= 32 && h->N1 >= 2 &&
-              !getenv("BIOEM_NO_SPLIT_LAST");
+    // (with the Nyquist split the blocks hold the H - 1 columns below N / 2: whole ones, or -- 192^2, 320^2, 448^2, which
+    // were planned that way -- a last one of 32, and then the split is not optional)
+    const int cols = h->nyq ? h->H - 1 : h->H;
+    const int nblkF = (cols + 63) / 64, rem = cols - (nblkF - 1) * 64;
+    a.split = h->fast && !h->fastm2 && !h->wide2 && !h->rowsK && rem <= 32 && h->N1 >= 2 &&
+              (h->nyq || !getenv("BIOEM_NO_SPLIT_LAST"));
   }
   a.pchunk = h->pchunk > 0 ? std::min(h->pchunk, h->nMaps) : h->nMaps;
   if (a.pchunk >= 8) // a multiple of 8: a particle then stays on one XCD (65 particles: chunks of 64 + 1, 43.6 -> 45.3 M/s)

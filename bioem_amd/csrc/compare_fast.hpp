@@ -446,7 +446,7 @@ __global__ __launch_bounds__(256, BIOEM_FAST_WAVES_PER_SIMD) void k_compare_fast
   };
   const int rowbase = is_static ? ((wactive ? grp : 0) * NR - mD + WD) * TS : row_of(0);
 
-  const int nblk = NYQ ? (H - 1) / 64 : (H + 63) / 64;
+  const int nblk = NYQ ? (H - 1 + 63) / 64 : (H + 63) / 64; // (Nyquist split: whole blocks, or a last one of 32 columns)
   // Operand stream (software pipelined across k1 iterations AND column blocks): the (k1, k2-pair) loads of a
   // lane walk t = k1*16 + k2p with a constant stride of H float4; a 4-deep ring of (F, C) pairs keeps 8 dwordx4
   // loads (8 KiB per wave) in flight, re-issued as soon as a slot is consumed.  The ring runs on into the first
@@ -459,11 +459,12 @@ __global__ __launch_bounds__(256, BIOEM_FAST_WAVES_PER_SIMD) void k_compare_fast
   // recombination twiddles -- wave-uniform as everywhere --, w^(dx (k1 + sHalf)) = w^(dx k1) w^(dx sHalf): the high half's
   // sums are turned by w^(dx sHalf) once, after the loop, and the halves added with v_permlane32_swap.  The pass then
   // costs sHalf instead of N1 steps: 1.5 instead of 2 passes at 160^2.
+  constexpr bool SPLIT_OK = !(NYQ && R == 32); // (the 32-point Nyquist kernels have no registers left for it)
   const int sHalf = (N1 + 1) >> 1;
   const int hsel = lane >> 5;
   const unsigned halfoff = (unsigned) (hsel * sHalf * R2) * rowbytes;
   auto lane_offset = [&](int b) -> unsigned { // byte offset of this lane's column (and half) in column block b
-    const bool sp = !NYQ && a.split && b == nblk - 1;
+    const bool sp = SPLIT_OK && a.split && b == nblk - 1;
     const int kyb = b * 64 + (sp ? (lane & 31) : lane);
     return (unsigned) (kyb < H ? kyb : H - 1) * 16u + (sp ? halfoff : 0u);
   };
@@ -479,7 +480,7 @@ __global__ __launch_bounds__(256, BIOEM_FAST_WAVES_PER_SIMD) void k_compare_fast
   }
   for (int blk = 0; blk < nblk; blk++)
   {
-    const bool split = !NYQ && a.split && blk == nblk - 1; // (never with the Nyquist split: whole blocks only)
+    const bool split = SPLIT_OK && a.split && blk == nblk - 1;
     const int n1 = split ? sHalf : N1;
     const int ttotal = R2 * n1;
     const int ky = blk * 64 + (split ? (lane & 31) : lane);

@@ -361,6 +361,29 @@ bool plan_window_kernel(KernelPlan &P, int N, int H, int winD, bool untiled)
       }
       return false;
     }
+    // 64^2 and 192^2 (N / 2 = 32 mod 64): the Nyquist column by direct summation as for 128^2 / 256^2, and the 32 columns
+    // that remain beyond the whole blocks as a split block (compare_fast.hpp) -- 1.5 passes instead of 2 at 192^2: +-10 px
+    // 62.3 -> 63.8 M/s, +-5 px 72.4 -> 77.2.  The 32-point Nyquist kernels have no registers left for the split: 16
+    // points (21 rows) / 8 points (11 rows) only, which pays at 320^2 with 21 rows still (25.5 -> 26.7 M/s) and no longer
+    // with 11 rows (-3 %) or at 448^2 (-3 / -30 %).
+    const bool nyq32 = BIOEM_NYQUIST_SPLIT && !nyq && (N / 2) % 64 == 32 && (N <= 256 || (N == 320 && winD == 10)) &&
+                       !getenv("BIOEM_NO_SPLIT_LAST");
+    if (nyq32)
+    {
+      const int R = winD == 5 ? 8 : 16;
+      if (!(getenv("BIOEM_FAST_R") && R != atoi(getenv("BIOEM_FAST_R"))))
+        if (const fast_kernel_t fn = find_kernel(KF_FAST, winD, R, true, P.gs))
+        {
+          P.family = KF_FAST;
+          P.fn = fn;
+          P.fast = R / 2;
+          P.N1 = N / R;
+          P.nyq = true;
+          P.winD = winD;
+          P.ldsBytes = fast_lds_bytes(N, 2 * winD + 1, 4, false);
+          return true;
+        }
+    }
     std::vector<int> lens;
     if (nyq)
     { // 128^2, 256^2, ...: 32 points, and the shorter lengths that the sweep below found faster (128^2 +-5 px: 155 -> 173

@@ -1116,7 +1116,10 @@ def test_image_sizes_against_oracle(N, maxD, grid, fast, algo):
 @pytest.mark.parametrize("N,maxD,grid", [(60, 10, 1), (144, 10, 1), (150, 5, 1), (160, 10, 1), (160, 5, 1), (176, 20, 2),
                                          (190, 10, 1), (288, 10, 1), (300, 5, 1), (138, 9, 1),
                                          # ... and of k_compare_fastm (27 / 31 rows)
-                                         (160, 13, 1), (144, 15, 1), (150, 13, 1), (176, 26, 2), (288, 15, 1), (60, 13, 1)])
+                                         (160, 13, 1), (144, 15, 1), (150, 13, 1), (176, 26, 2), (288, 15, 1), (60, 13, 1),
+                                         # ... and N / 2 = 32 (mod 64): Nyquist column apart, the 32 columns beyond the
+                                         # whole blocks as a split block (planned that way: no unsplit pass to compare)
+                                         (192, 10, 1), (192, 5, 1), (192, 20, 2), (64, 10, 1), (64, 5, 1), (320, 10, 1)])
 @pytest.mark.parametrize("algo", [1, 2])
 def test_split_last_column_block_against_oracle(N, maxD, grid, algo, monkeypatch):
     from bioem_amd.synthetic import Workload
@@ -1129,10 +1132,11 @@ def test_split_last_column_block_against_oracle(N, maxD, grid, algo, monkeypatch
         _, got = run_workload(W, 0, nO)
         assert_workload_matches(got, want, const, sel)
         # and the unsplit pass of the same kernel (BIOEM_NO_SPLIT_LAST is read at every launch): the same arg-max tuples
-        monkeypatch.setenv("BIOEM_NO_SPLIT_LAST", "1")
-        _, plain = run_workload(W, 0, nO)
-        assert_workload_matches(plain, want, const, sel)
-        assert np.array_equal(got["orient"], plain["orient"]) and np.array_equal(got["cent_x"], plain["cent_x"])
+        if N not in (64, 192) and (N, maxD) != (320, 10):
+            monkeypatch.setenv("BIOEM_NO_SPLIT_LAST", "1")
+            _, plain = run_workload(W, 0, nO)
+            assert_workload_matches(plain, want, const, sel)
+            assert np.array_equal(got["orient"], plain["orient"]) and np.array_equal(got["cent_x"], plain["cent_x"])
     finally:
         W.engine.close()
 

@@ -60,7 +60,8 @@ def test_headline_shapes():
     L = eng.load_library()
     assert plan(L, 224, 10, 1, 1) == "k_compare_fast<10, 16, false, 1>"            # BASELINE config 2 / 3
     assert plan(L, 288, 10, 1, 1) == "k_compare_fast<10, 32, false, 1>"            # beyond 256 pixels: the longest length
-    assert plan(L, 64, 5, 1, 1) == "k_compare_fast<5, 8, false, 1>"                # 11 rows, small image: 8 points
+    assert plan(L, 96, 5, 1, 1) == "k_compare_fast<5, 8, false, 1>"                # 11 rows, small image: 8 points
+    assert plan(L, 192, 10, 1, 1) == "k_compare_fast<10, 16, true, 1>"             # N / 2 = 32 (mod 64): Nyquist apart + split
     assert plan(L, 128, 10, 1, 1) == "k_compare_fast<10, 16, true, 1>"             # config 1 / 4 (Nyquist split)
     assert plan(L, 256, 10, 1, 1) == "k_compare_fast<10, 16, true, 1>"             # config 5
     assert plan(L, 384, 10, 1, 1) == "k_compare_fast<10, 32, true, 1>"
