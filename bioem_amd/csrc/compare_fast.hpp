@@ -344,6 +344,9 @@ __device__ __forceinline__ void window_accumulate(const float2 *Tl, const float2
 #ifndef BIOEM_FAST_WAVES_PER_SIMD
 #define BIOEM_FAST_WAVES_PER_SIMD 3
 #endif
+#ifndef BIOEM_FAST_HALVES
+#define BIOEM_FAST_HALVES 0
+#endif
 // NYQ (N/2 a multiple of 64, e.g. 128 and 256): the half spectrum has N/2 + 1 columns, one more than fills the
 // 64-lane column blocks, and a whole extra block pass for that single Nyquist column would cost 1/2 (128) or 1/3
 // (256) of the kernel.  Instead k_nyquist_rows (below) forms the 2*WD+1 column-transform outputs of that column
@@ -361,10 +364,13 @@ __global__ __launch_bounds__(256, BIOEM_FAST_WAVES_PER_SIMD) void k_compare_fast
   constexpr int R2 = R / 2;            // rows (k2 pairs) per k1 step
   // depth of the operand ring: must divide R2 so that a ring slot is a compile-time function of the k2 pair
   // (R = 30: a ring of 3, not 5 -- 16 registers the 21-row window of that length needs)
-  constexpr int RD = (R2 % 4 == 0) ? 4 : (R2 == 15) ? 3 : (R2 % 5 == 0) ? 5 : (R2 % 3 == 0) ? 3 : (R2 % 2 == 0) ? 2 : 1;
+#ifndef BIOEM_FAST_RING
+#define BIOEM_FAST_RING 0
+#endif
+  constexpr int RD = BIOEM_FAST_RING ? BIOEM_FAST_RING : (R2 % 4 == 0) ? 4 : (R2 == 15) ? 3 : (R2 % 5 == 0) ? 5 : (R2 % 3 == 0) ? 3 : (R2 % 2 == 0) ? 2 : 1;
   constexpr int NR = (WD <= 5) ? 3 : 7; // accumulators (window rows) per lane
   // T row stride in float2 (64 or 32 columns + 2 pad: row groups land on different banks)
-  constexpr int TS = 66;
+  constexpr int TS = BIOEM_FAST_HALVES ? 34 : 66;
   extern __shared__ __align__(16) unsigned char smem[];
   const int N = a.N, H = a.H, N1 = a.N1;
   float2 *twl = reinterpret_cast<float2 *>(smem);                            // N+1 (+pad)
@@ -570,6 +576,36 @@ __global__ __launch_bounds__(256, BIOEM_FAST_WAVES_PER_SIMD) void k_compare_fast
       wgt = 0.f;
     // T block of THIS wave only: LDS operations of one wave execute in order, so a wave-level fence (no
     // s_barrier) is enough; BIOEM_BLOCK_BARRIER=1 restores block barriers (keeps the 4 waves in lock-step)
+#if BIOEM_FAST_HALVES
+    for (int hx = 0; hx < 2; hx++)
+    {
+      const int npairs = min(16, ((H - blk * 64 + 1) >> 1) - 16 * hx);
+      if (npairs <= 0)
+        break;
+      WAVE_OR_BLOCK_SYNC(); // previous window reads are done
+      if (hsel == hx)
+      {
+#pragma unroll
+        for (int d = 0; d < NW; d++)
+          Tl[d * TS + (lane & 31)] = make_float2(Tr[d] * wgt, Ti[d] * wgt);
+      }
+      WAVE_OR_BLOCK_SYNC();
+      const int idx0 = (int) (((long long) (blk * 64 + 32 * hx) * step) % N);
+      if (is_static)
+      {
+        const int rowoff[NR] = {rowbase};
+        window_accumulate<NR, true, 16, TS>(Tl, twl, N, step, idx0, rowoff, nr, acc, npairs);
+      }
+      else
+      {
+        int rowoff[NR];
+#pragma unroll
+        for (int r = 0; r < NR; r++)
+          rowoff[r] = row_of(r);
+        window_accumulate<NR, false, 16, TS>(Tl, twl, N, step, idx0, rowoff, nr, acc, npairs);
+      }
+    }
+#else
     {
       WAVE_OR_BLOCK_SYNC(); // previous window reads are done
 #pragma unroll
@@ -596,6 +632,7 @@ __global__ __launch_bounds__(256, BIOEM_FAST_WAVES_PER_SIMD) void k_compare_fast
         window_accumulate<NR, false, 32, TS>(Tl, twl, N, step, idx0, rowoff, nr, acc, npairs);
       }
     }
+#endif
   }
   if (NYQ)
   {

@@ -103,6 +103,9 @@ size_t compare_lds_bytes(int N, int H, int NW, int waves)
   const size_t dispBytes = ((size_t) NW * 4 + 255) & ~(size_t) 255;
   return (size_t) ((N + 2) & ~1) * 8 + dispBytes + (size_t) waves * NW * Hs * 8;
 }
+#ifndef BIOEM_FAST_HALVES
+#define BIOEM_FAST_HALVES 0
+#endif
 size_t fast_lds_bytes(int N, int NW, int waves, bool half)
 { // fast / rows kernels: twiddles + displacement list + log table + per-wave T block [NW][66] ([NW][34] half exchange)
   return (size_t) ((N + 2) & ~1) * 8 + 256 + 1024 + (size_t) waves * NW * (half ? 34 : 66) * 8;
@@ -436,7 +439,7 @@ bool plan_window_kernel(KernelPlan &P, int N, int H, int winD, bool untiled)
         P.N1 = N / R;
         P.nyq = nyq;
         P.winD = wd;
-        P.ldsBytes = fast_lds_bytes(N, 2 * wd + 1, 4, false);
+        P.ldsBytes = fast_lds_bytes(N, 2 * wd + 1, 4, BIOEM_FAST_HALVES);
         return true;
       }
     }
