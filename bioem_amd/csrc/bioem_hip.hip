@@ -95,6 +95,8 @@ struct bioem_hip_ctx
   PD pd;
   int nMaps = 0, nAngles = 0, nCTF = 0, algo = 1;
   int N = 0, H = 0, M = 0;
+  int Hp = 0;    // row-pair pitch of the comparison layout in 16-byte words (H, or H + 15: comparison_pitch)
+  size_t Mc = 0; // float2 per image of the comparison layout, N * Hp
   int fast = 0, N1 = 0, winD = 0; // winD = template window half width used by the fast kernel
   int pchunk = 128;               // particle chunk of the fast kernel's block order (0 = all particles); measured:
                                   // 1 000 particles 6.73 -> 6.56 ms, 10 000 particles (2 GB, beyond the Infinity
@@ -393,6 +395,7 @@ int launch_compare_fold(bioem_hip_ctx *h, const BatchBuf &bb, int nOC, int orien
   a.ldPart = h->maxOC;
   a.N = h->N;
   a.H = h->H;
+  a.Hp = h->Hp;
   a.N1 = h->N1;
   a.nd = h->nd;
   a.maxD = h->pd.maxDisplaceCenter;
@@ -813,7 +816,7 @@ int compat_flush(bioem_hip_ctx *h)
   HIP_CHECK(h, hipMemcpyAsync(r.dIds, r.hIds, sizeof(int2) * n, hipMemcpyHostToDevice, h->stream));
   HIP_CHECK(h, hipMemcpyAsync(r.dSeg, r.hSeg, sizeof(int4) * nSeg, hipMemcpyHostToDevice, h->stream));
   hipLaunchKernelGGL(k_reorder, dim3(std::min(2048, 8 * n)), dim3(256), 0, h->stream, r.dStage, bb.conv, n, h->N, h->H,
-                     h->fast, h->N1);
+                     h->fast, h->N1, h->Hp);
   HIP_CHECK(h, hipGetLastError());
   if (launch_compare_fold(h, bb, n, 0, 0, 1, r.dIds, r.dSeg, nSeg))
     return 1;
@@ -840,19 +843,19 @@ int convolve_batch(bioem_hip_ctx *h, const BatchBuf &bb, hipStream_t st, int nO,
     // longer than the 960 additions)
     if (nC <= 4)
       hipLaunchKernelGGL((k_convolve_sums<4, 4>), dim3(1, (nO + 3) / 4), dim3(kConvThreads), conv_lanes_lds(4 * nC), st,
-                         bb.specRef, h->dCTF, h->dCtfParam, h->N, h->H, h->fast, h->N1, c0, nC, nO, 4 * nC, bb.conv, bb.params);
+                         bb.specRef, h->dCTF, h->dCtfParam, h->N, h->H, h->fast, h->N1, c0, nC, nO, 4 * nC, bb.conv, bb.params, h->Hp);
     else if (nC == 5)
       hipLaunchKernelGGL((k_convolve_sums<3, 5>), dim3(1, (nO + 2) / 3), dim3(kConvThreads), conv_lanes_lds(15), st, bb.specRef,
-                         h->dCTF, h->dCtfParam, h->N, h->H, h->fast, h->N1, c0, nC, nO, 15, bb.conv, bb.params);
+                         h->dCTF, h->dCtfParam, h->N, h->H, h->fast, h->N1, c0, nC, nO, 15, bb.conv, bb.params, h->Hp);
     else
       hipLaunchKernelGGL((k_convolve_sums<3, 6>), dim3((nC + 5) / 6, (nO + 2) / 3), dim3(kConvThreads), conv_lanes_lds(18), st,
-                         bb.specRef, h->dCTF, h->dCtfParam, h->N, h->H, h->fast, h->N1, c0, nC, nO, 18, bb.conv, bb.params);
+                         bb.specRef, h->dCTF, h->dCtfParam, h->N, h->H, h->fast, h->N1, c0, nC, nO, 18, bb.conv, bb.params, h->Hp);
     HIP_CHECK(h, hipGetLastError());
     return 0;
   }
   const int M4 = (int) ((h->M + 3) & ~(size_t) 3);
   hipLaunchKernelGGL(k_convolve, dim3(nC, nO), dim3(256), 0, st, bb.specRef, h->dCTF, h->dCtfParam, h->N, h->H,
-                     h->fast, h->N1, c0, bb.conv, bb.scratch, M4, bb.params);
+                     h->fast, h->N1, c0, bb.conv, bb.scratch, M4, bb.params, h->Hp);
   HIP_CHECK(h, hipGetLastError());
   // the ordered Parseval sums of all nC x nO spectra side by side: four sequential chains per wave
   hipLaunchKernelGGL(k_parseval_ordered, dim3((nC * nO + 3) / 4), dim3(64), 0, st, bb.scratch, (int) h->M, M4, nC * nO,
@@ -986,10 +989,23 @@ static int create_impl(bioem_hip_handle *out, int device, const bioem_hip_param_
                                      (int) h->ldsBytes));
   }
   const int mD = maxD / h->gs;
+  // Pitch of the comparison layout.  A lane block of the fast kernels keeps eight rows of one 64-column block in flight;
+  // with N a multiple of 128 a row pair is 16 B more than a multiple of 1 KiB (4 112 B at 512^2) and all of them start
+  // in the same few L2 channels.  Fifteen more words make the pitch an odd number of 256-byte lines (timing build,
+  // round 4: 512^2 8.3 -> 10.1 M/s, 384^2 17.8 -> 19.2, 256^2 40.1 -> 42.0; the real thing, same box: +20 / +6.7 / +3 % at
+  // +-5 and +-10 px, +1...6 % on the matrix-core families; 128^2 gains nothing and loses 1...3 % on few-particle jobs: not
+  // padded).  Those sizes are Nyquist-split plans of the one-wave-per-comparison families -- only their kernels read the
+  // pitch from the arguments (NYQ ? a.Hp : H); every other plan keeps Hp = H.
+  h->Hp = h->H;
+  const bool directCC = getenv("BIOEM_CC_DIRECT") && atoi(getenv("BIOEM_CC_DIRECT")) != 0; // (its own kernels read conv)
+  if (h->nyq && h->fast && !h->wide2 && !h->rowsK && !h->tileT && !directCC && N % 128 == 0 && N >= 256 &&
+      !getenv("BIOEM_NO_PITCH_PAD"))
+    h->Hp = h->H + 15;
+  h->Mc = (size_t) N * h->Hp;
 
   // batch sizing: conv buffer <= ~96 MiB, partial buffer <= ~128 MiB
   const size_t M = (size_t) h->M;
-  size_t ocCap = (96u << 20) / (M * sizeof(float2));
+  size_t ocCap = (96u << 20) / (h->Mc * sizeof(float2));
   // (tiled wide windows keep one partial per tile and comparison besides the merged one)
   const size_t partBuffers = 1 + (h->tileT ? (size_t) h->tilesPerAxis * h->tilesPerAxis : 0);
   size_t partCap = (128u << 20) / ((size_t) nMaps * sizeof(Partial));
@@ -1008,7 +1024,7 @@ static int create_impl(bioem_hip_handle *out, int device, const bioem_hip_param_
     if (perOrient * 64 < 320000 && !getenv("BIOEM_FIXED_BATCH"))
     {
       obMax = (int) std::min<long long>(2048, ((320000 + perOrient - 1) / perOrient + 63) / 64 * 64);
-      ocCap = std::min(partCap, (size_t) (1024u << 20) / (M * sizeof(float2)));
+      ocCap = std::min(partCap, (size_t) (1024u << 20) / (h->Mc * sizeof(float2)));
     }
   }
   int OB = (int) (ocCap / (size_t) nCTF);
@@ -1026,7 +1042,7 @@ static int create_impl(bioem_hip_handle *out, int device, const bioem_hip_param_
   h->maxOC = OB * nCTF;
   h->chunkB = OB > 32 ? OB : 32;
 
-  HIP_CHECK(h, hipMalloc(&h->dRef, sizeof(float2) * M * nMaps));
+  HIP_CHECK(h, hipMalloc(&h->dRef, sizeof(float2) * h->Mc * nMaps));
   HIP_CHECK(h, hipMalloc(&h->dSumRef, sizeof(float) * nMaps));
   HIP_CHECK(h, hipMalloc(&h->dSumsqRef, sizeof(float) * nMaps));
   HIP_CHECK(h, hipMalloc(&h->dCTF, sizeof(float2) * M * nCTF));
@@ -1041,7 +1057,7 @@ static int create_impl(bioem_hip_handle *out, int device, const bioem_hip_param_
   HIP_CHECK(h, hipMalloc(&h->dRowSpec, sizeof(double2) * (size_t) h->chunkB * M));
   HIP_CHECK(h, hipMalloc(&h->dSpecRef, sizeof(float2) * (size_t) h->chunkB * M));
   HIP_CHECK(h, hipMalloc(&h->dScratch, sizeof(float) * (size_t) ((h->maxOC + 31) & ~31) * ((M + 3) & ~(size_t) 3)));
-  HIP_CHECK(h, hipMalloc(&h->dConv, sizeof(float2) * (size_t) h->maxOC * M));
+  HIP_CHECK(h, hipMalloc(&h->dConv, sizeof(float2) * (size_t) h->maxOC * h->Mc));
   HIP_CHECK(h, hipMalloc(&h->dParams, sizeof(bioem_hip_param5) * h->maxOC));
   HIP_CHECK(h, hipMalloc(&h->dPostC, sizeof(double2) * h->maxOC));
   HIP_CHECK(h, hipMalloc(&h->dPartials, sizeof(Partial) * (size_t) nMaps * h->maxOC));
@@ -1104,7 +1120,7 @@ static int create_impl(bioem_hip_handle *out, int device, const bioem_hip_param_
   HIP_CHECK(h, hipMalloc(&h->dRowSpec2, sizeof(double2) * (size_t) h->OB * M));
   HIP_CHECK(h, hipMalloc(&h->dSpecRef2, sizeof(float2) * (size_t) h->OB * M));
   HIP_CHECK(h, hipMalloc(&h->dScratch2, sizeof(float) * (size_t) ((h->maxOC + 31) & ~31) * ((M + 3) & ~(size_t) 3)));
-  HIP_CHECK(h, hipMalloc(&h->dConv2, sizeof(float2) * (size_t) h->maxOC * M));
+  HIP_CHECK(h, hipMalloc(&h->dConv2, sizeof(float2) * (size_t) h->maxOC * h->Mc));
   HIP_CHECK(h, hipMalloc(&h->dParams2, sizeof(bioem_hip_param5) * h->maxOC));
   HIP_CHECK(h, hipMalloc(&h->dPostC2, sizeof(double2) * h->maxOC));
   for (int i = 0; i < 2; i++)
@@ -1305,8 +1321,8 @@ int bioem_hip_upload_particles(bioem_hip_handle h, const float *refFFT, const fl
     const int n = std::min(h->chunkB, h->nMaps - b);
     HIP_CHECK(h, hipMemcpyAsync(h->dSpecRef, refFFT + 2 * M * (size_t) b, sizeof(float2) * M * n,
                                 hipMemcpyHostToDevice, h->stream));
-    hipLaunchKernelGGL(k_reorder, dim3(1024), dim3(256), 0, h->stream, h->dSpecRef, h->dRef + M * (size_t) b, n, h->N,
-                       h->H, h->fast, h->N1);
+    hipLaunchKernelGGL(k_reorder, dim3(1024), dim3(256), 0, h->stream, h->dSpecRef, h->dRef + h->Mc * (size_t) b, n, h->N,
+                       h->H, h->fast, h->N1, h->Hp);
     HIP_CHECK(h, hipGetLastError());
     HIP_CHECK(h, hipStreamSynchronize(h->stream));
   }
@@ -1335,8 +1351,8 @@ int bioem_hip_upload_particle_maps(bioem_hip_handle h, const float *maps)
       hipFree(dMaps);
       return 1;
     }
-    hipLaunchKernelGGL(k_reorder, dim3(1024), dim3(256), 0, h->stream, h->dSpecRef, h->dRef + M * (size_t) b, n, N,
-                       h->H, h->fast, h->N1);
+    hipLaunchKernelGGL(k_reorder, dim3(1024), dim3(256), 0, h->stream, h->dSpecRef, h->dRef + h->Mc * (size_t) b, n, N,
+                       h->H, h->fast, h->N1, h->Hp);
     HIP_CHECK(h, hipGetLastError());
     HIP_CHECK(h, hipStreamSynchronize(h->stream));
   }
@@ -2071,8 +2087,8 @@ int bioem_hip_debug_convolution(bioem_hip_handle h, int iOrient, int iConv, floa
     return 1;
   const size_t M = (size_t) h->M;
   float2 *tmp = h->dSpecRef + M; // chunkB >= 32 slots; slot 0 holds the projection spectrum
-  hipLaunchKernelGGL(k_unreorder, dim3(256), dim3(256), 0, h->stream, h->dConv + M * (size_t) iConv, tmp, 1, h->N,
-                     h->H, h->fast, h->N1);
+  hipLaunchKernelGGL(k_unreorder, dim3(256), dim3(256), 0, h->stream, h->dConv + h->Mc * (size_t) iConv, tmp, 1, h->N,
+                     h->H, h->fast, h->N1, h->Hp);
   HIP_CHECK(h, hipGetLastError());
   HIP_CHECK(h, hipMemcpyAsync(spec_out, tmp, sizeof(float2) * M, hipMemcpyDeviceToHost, h->stream));
   bioem_hip_param5 q;
@@ -2090,8 +2106,8 @@ int bioem_hip_debug_particles(bioem_hip_handle h, float *refFFT_out, float *sum_
   for (int b = 0; b < h->nMaps; b += h->chunkB)
   {
     const int n = std::min(h->chunkB, h->nMaps - b);
-    hipLaunchKernelGGL(k_unreorder, dim3(1024), dim3(256), 0, h->stream, h->dRef + M * (size_t) b, h->dSpecRef, n, h->N,
-                       h->H, h->fast, h->N1);
+    hipLaunchKernelGGL(k_unreorder, dim3(1024), dim3(256), 0, h->stream, h->dRef + h->Mc * (size_t) b, h->dSpecRef, n, h->N,
+                       h->H, h->fast, h->N1, h->Hp);
     HIP_CHECK(h, hipGetLastError());
     HIP_CHECK(h, hipMemcpyAsync(refFFT_out + 2 * M * (size_t) b, h->dSpecRef, sizeof(float2) * M * n,
                                 hipMemcpyDeviceToHost, h->stream));

@@ -23,6 +23,7 @@ struct CompareArgs
   Partial *partials; // [nMaps][ldPart]
   int ldPart;
   int N, H, N1, nd, maxD, nOC, nMaps, algo;
+  int Hp; // row-pair pitch of ref / conv in 16-byte words: H, or H + 15 (fast families with the Nyquist split; bioem_hip.hip)
   int pchunk; // particles per block-order chunk of the fast kernel
   int gs;     // pixels per window row of the fast kernel (template GS)
   // window tiles (wide windows are covered by several launches over phase-shifted conv spectra): only the first

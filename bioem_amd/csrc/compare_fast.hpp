@@ -410,7 +410,8 @@ __global__ __launch_bounds__(256, BIOEM_FAST_WAVES_PER_SIMD) void k_compare_fast
   const int oc_raw = ocg * 4 + wave;
   const bool oc_valid = oc_raw < a.nOC;
   const int oc = oc_valid ? oc_raw : a.nOC - 1;
-  const size_t M = (size_t) N * H;
+  const int Hp = NYQ ? a.Hp : H; // row-pair pitch in 16-byte words: padded for Nyquist-split plans only (bioem_hip.hip)
+  const size_t M = (size_t) N * Hp;
   // buffer descriptors built from wave-uniform values only (blockIdx / readfirstlane'd wave id)
   // timing-only ablation builds (never shipped): a zero-record descriptor drops the loads of one operand while
   // the instruction stream and waits stay (cdna_hip_programming.md, profiling: pricing one buffer's traffic)
@@ -458,7 +459,7 @@ __global__ __launch_bounds__(256, BIOEM_FAST_WAVES_PER_SIMD) void k_compare_fast
   // loads (8 KiB per wave) in flight, re-issued as soon as a slot is consumed.  The ring runs on into the first
   // rows of the NEXT column block, so those loads fly during the T exchange / window phase of this block.
   // Addressing: buffer loads -- 128-bit descriptor (SGPRs), one 32-bit lane offset (VGPR), row offset in an SGPR.
-  const unsigned rowbytes = (unsigned) H * 16u;
+  const unsigned rowbytes = (unsigned) Hp * 16u;
   // Split last block (a.split: it holds at most 32 columns, e.g. 17 of the 81 at 160^2): lane l and lane l + 32 take the
   // SAME column, the low half the k1 steps 0 .. sHalf - 1, the high half sHalf .. N1 - 1 (one past the end with an odd
   // N1: those rows lie beyond the buffer and read as zeros).  Inside the loop both halves use the low half's
@@ -709,7 +710,7 @@ __global__ __launch_bounds__(256) void k_nyquist_rows(const CompareArgs a)
   const int t = Q == 1 ? threadIdx.x : threadIdx.x & 63;
   const int p = tp * (16 / Q) + (t >> 4), oc = to * 16 + (t & 15);
   const bool valid = p < a.nMaps && oc < a.nOC;
-  const size_t M = (size_t) N * H;
+  const size_t M = (size_t) N * a.Hp; // an image of the comparison layout (Hp >= H: its row-pair pitch)
   const float2 *F = a.ref + (size_t) (valid ? p : 0) * M;
   const float2 *C = a.conv + (size_t) (valid ? oc : 0) * M;
   float acc[NW];
@@ -728,7 +729,7 @@ __global__ __launch_bounds__(256) void k_nyquist_rows(const CompareArgs a)
     for (int u = 0; u < NB; u++)
     {
       // the two k2 of a pair are adjacent in the comparison layout: one 16-byte load per operand
-      const size_t li = ((size_t) (rp0 + u) * H + N / 2) * 2;
+      const size_t li = ((size_t) (rp0 + u) * a.Hp + N / 2) * 2;
       cb[u] = *reinterpret_cast<const float4 *>(C + li);
       fb[u] = *reinterpret_cast<const float4 *>(F + li);
     }

@@ -87,7 +87,8 @@ __global__ __launch_bounds__(256, 3) void k_compare_fastm(const CompareArgs a)
   const int oc_raw = ocg * 4 + wave;
   const bool oc_valid = oc_raw < a.nOC;
   const int oc = oc_valid ? oc_raw : a.nOC - 1;
-  const size_t M = (size_t) N * H;
+  const int Hp = NYQ ? a.Hp : H; // row-pair pitch in 16-byte words: padded for Nyquist-split plans only (bioem_hip.hip)
+  const size_t M = (size_t) N * Hp;
   const auto rsrcF = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(const_cast<float2 *>(a.ref + (size_t) p * M)), 0,
                                                        (int) (M * sizeof(float2)), 0x00020000);
   const auto rsrcC = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(const_cast<float2 *>(a.conv + (size_t) oc * M)), 0,
@@ -102,7 +103,7 @@ __global__ __launch_bounds__(256, 3) void k_compare_fastm(const CompareArgs a)
   floatx16 Dfin;
 
   const int nblk = NYQ ? (H - 1) / 64 : (H + 63) / 64;
-  const unsigned rowbytes = (unsigned) H * 16u;
+  const unsigned rowbytes = (unsigned) Hp * 16u;
   // split last block (a.split, as in k_compare_fast: at most 32 columns, shared by the half-waves -- the low half the k1
   // steps 0 .. sHalf - 1, the high half the rest, its sums turned by w^(dx sHalf) and added after the loop)
   // (the 31-row kernels with 10- and 8-point FFTs have no registers left for it: they keep the whole pass)

@@ -110,7 +110,8 @@ __global__ __launch_bounds__(256, 3) void k_compare_fastm2(const CompareArgs a)
   const int oc_raw = ocg * 4 + wave;
   const bool oc_valid = oc_raw < a.nOC;
   const int oc = oc_valid ? oc_raw : a.nOC - 1;
-  const size_t M = (size_t) N * H;
+  const int Hp = NYQ ? a.Hp : H; // row-pair pitch in 16-byte words: padded for Nyquist-split plans only (bioem_hip.hip)
+  const size_t M = (size_t) N * Hp;
   const auto rsrcF = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(const_cast<float2 *>(a.ref + (size_t) p * M)), 0,
                                                        (int) (M * sizeof(float2)), 0x00020000);
   const auto rsrcC = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(const_cast<float2 *>(a.conv + (size_t) oc * M)), 0,
@@ -128,7 +129,7 @@ __global__ __launch_bounds__(256, 3) void k_compare_fastm2(const CompareArgs a)
   const int Hlim = NYQ ? H - 1 : H; // columns of the passes (the Nyquist column of 128^2 / 256^2 comes from k_nyquist_rows)
   const int npass = (Hlim + 31) / 32;
   const int nS = (N1 + 1) >> 1; // steps: k1 pairs
-  const unsigned rowbytes = (unsigned) H * 16u;
+  const unsigned rowbytes = (unsigned) Hp * 16u;
   const unsigned halfoff = (unsigned) hh * (unsigned) R2 * rowbytes; // the high half reads k1 = 2 s + 1: R2 row pairs on
   u32x4 rf[RD], rc[RD];
   {

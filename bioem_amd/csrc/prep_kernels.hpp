@@ -12,40 +12,43 @@ namespace
 //            (lane = ky reads 16 B = two k2 of one k1 -> fully coalesced dwordx4, and the R inputs
 //             of one register FFT arrive as R/2 such loads).  The `fast` argument carries R/2 (0 = generic).
 //   generic: reference layout kx*H + ky
+// Hp >= H is the pitch of a row pair in 16-byte words (comparison_pitch, bioem_hip.hip): H, or H + 15 where the rows
+// of a column block would otherwise all start in the same few L2 channels (N a multiple of 128); an image then
+// takes N * Hp float2.  The reference layout is never padded.
 // ------------------------------------------------------------------------------------------------
-__host__ __device__ inline size_t layout_index(int fast, int N1, int H, int kx, int ky)
+__host__ __device__ inline size_t layout_index(int fast, int N1, int H, int kx, int ky, int Hp = 0)
 {
   if (!fast)
     return (size_t) kx * H + ky;
   const int k1 = kx % N1, k2 = kx / N1;
-  return ((size_t) (k1 * fast + (k2 >> 1)) * H + ky) * 2 + (k2 & 1);
+  return ((size_t) (k1 * fast + (k2 >> 1)) * (Hp ? Hp : H) + ky) * 2 + (k2 & 1);
 }
 
 __global__ void k_reorder(const float2 *__restrict__ src, float2 *__restrict__ dst, int nImg, int N, int H, int fast,
-                          int N1)
+                          int N1, int Hp)
 {
-  const size_t M = (size_t) N * H;
+  const size_t M = (size_t) N * H, Mc = (size_t) N * Hp;
   const size_t total = M * nImg;
   for (size_t e = (size_t) blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t) gridDim.x * blockDim.x)
   {
     const size_t img = e / M;
     const int r = (int) (e - img * M);
     const int kx = r / H, ky = r - kx * H;
-    dst[img * M + layout_index(fast, N1, H, kx, ky)] = src[e];
+    dst[img * Mc + layout_index(fast, N1, H, kx, ky, Hp)] = src[e];
   }
 }
 
 __global__ void k_unreorder(const float2 *__restrict__ src, float2 *__restrict__ dst, int nImg, int N, int H,
-                            int fast, int N1)
+                            int fast, int N1, int Hp)
 {
-  const size_t M = (size_t) N * H;
+  const size_t M = (size_t) N * H, Mc = (size_t) N * Hp;
   const size_t total = M * nImg;
   for (size_t e = (size_t) blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t) gridDim.x * blockDim.x)
   {
     const size_t img = e / M;
     const int r = (int) (e - img * M);
     const int kx = r / H, ky = r - kx * H;
-    dst[e] = src[img * M + layout_index(fast, N1, H, kx, ky)];
+    dst[e] = src[img * Mc + layout_index(fast, N1, H, kx, ky, Hp)];
   }
 }
 
@@ -649,14 +652,14 @@ __global__ void k_map_sums(const float *__restrict__ maps, int NN, float *__rest
 __global__ void k_convolve(const float2 *__restrict__ proj, const float2 *__restrict__ ctf,
                            const float *__restrict__ ctfParam, int N, int H, int fast, int N1, int c0,
                            float2 *__restrict__ conv, float *__restrict__ scratch, int M4,
-                           bioem_hip_param5 *__restrict__ params)
+                           bioem_hip_param5 *__restrict__ params, int Hp)
 {
   const int c = c0 + blockIdx.x, ob = blockIdx.y;
   const int oc = ob * gridDim.x + blockIdx.x;
   const int M = N * H;
   const float2 *P = proj + (size_t) ob * M;
   const float2 *K = ctf + (size_t) c * M;
-  float2 *O = conv + (size_t) oc * M;
+  float2 *O = conv + (size_t) oc * N * Hp; // (Hp == H without the fast layout)
   float *S = scratch + (size_t) oc * M4;
   const int even = ((N & 1) == 0);
   const int jend = even ? H - 1 : H;
@@ -696,7 +699,7 @@ __global__ void k_convolve(const float2 *__restrict__ proj, const float2 *__rest
       float2 o0, o1;
       element(i0, j, o0);
       element(i0 + N1, j, o1);
-      reinterpret_cast<float4 *>(O)[(size_t) rp * H + j] = make_float4(o0.x, o0.y, o1.x, o1.y);
+      reinterpret_cast<float4 *>(O)[(size_t) rp * Hp + j] = make_float4(o0.x, o0.y, o1.x, o1.y);
     }
   }
   else
@@ -825,7 +828,7 @@ template <int R, int NC>
 __global__ __launch_bounds__(kConvThreads) void
 k_convolve_sums(const float2 *__restrict__ proj, const float2 *__restrict__ ctf, const float *__restrict__ ctfParam,
                  int N, int H, int fast, int N1, int c0, int nC, int nO, int rows, float2 *__restrict__ conv,
-                 bioem_hip_param5 *__restrict__ params)
+                 bioem_hip_param5 *__restrict__ params, int Hp)
 {
   extern __shared__ __align__(16) float terms[]; // [2][rows][kConvStride], rows >= R x CTFs of the block
   __shared__ float sC[kLaneRows];
@@ -833,6 +836,7 @@ k_convolve_sums(const float2 *__restrict__ proj, const float2 *__restrict__ ctf,
   const int nJ = min(R, nO - ob0);
   const int nCb = min(NC, nC - cg);
   const int M = N * H;
+  const size_t Mc = (size_t) N * Hp; // an image of the comparison layout (Hp == H without the fast layout)
   const int even = ((N & 1) == 0);
   const int jend = even ? H - 1 : H;
   const float2 *K0 = ctf + (size_t) (c0 + cg) * M;
@@ -862,7 +866,7 @@ k_convolve_sums(const float2 *__restrict__ proj, const float2 *__restrict__ ctf,
     {
       const int k2 = i / N1, k1i = i - k2 * N1;
       L.first = !(k2 & 1);
-      L.word = (k1i * fast + (k2 >> 1)) * H + j;
+      L.word = (k1i * fast + (k2 >> 1)) * Hp + j;
       partner = L.first ? L.ij + N1 * H : L.ij;
     }
 #pragma unroll
@@ -888,12 +892,12 @@ k_convolve_sums(const float2 *__restrict__ proj, const float2 *__restrict__ ctf,
     {
       if (q >= nJ)
         break;
-      float2 *O0 = conv + ((size_t) (ob0 + q) * nC + cg) * M;
+      float2 *O0 = conv + ((size_t) (ob0 + q) * nC + cg) * Mc;
 #pragma unroll
       for (int c = 0; c < NC; c++)
         if (c < nCb)
         {
-          float2 *O = O0 + (size_t) c * M;
+          float2 *O = O0 + (size_t) c * Mc;
           const float2 k = L.kv[c];
           float2 v;
           v.x = (L.p[q].x * k.x + L.p[q].y * k.y);

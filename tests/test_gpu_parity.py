@@ -92,7 +92,7 @@ def test_native_path_matches_oracle_and_reference(name):
         E.close()
 
 
-@pytest.mark.parametrize("name", ["g10_n64", "g1_n48", "g7_n224"])
+@pytest.mark.parametrize("name", ["g10_n64", "g1_n48", "g7_n224", "g20_n256"])  # (256^2: the padded pitch)
 def test_reference_compatible_compare_entry(name):
     """bioem_hip_compare == bioem::compareRefMaps: host-prepared conv spectra in the 2-slot pipeline buffers
     (bioem.cpp:825-853), several convs per call, asynchronous enqueue."""
@@ -123,7 +123,7 @@ def test_reference_compatible_compare_entry(name):
 
 
 @pytest.mark.parametrize("name,split_ctf", [("g10_n64", False), ("g4_n32_angles", True), ("g2_n128", False),
-                                            ("g13_n32_psf_writectf", True)])
+                                            ("g13_n32_psf_writectf", True), ("g20_n256", True)])
 def test_staged_device_entries_equal_the_fused_entry(name, split_ctf):
     """bioem_hip_project / _convolve / _compare_device (createProjection, createConvolutedProjectionMap and compareRefMaps
     as separate asynchronous batched entries, everything device-resident) against bioem_hip_project_convolve_compare
@@ -1139,6 +1139,33 @@ def test_split_last_column_block_against_oracle(N, maxD, grid, algo, monkeypatch
             assert np.array_equal(got["orient"], plain["orient"]) and np.array_equal(got["cent_x"], plain["cent_x"])
     finally:
         W.engine.close()
+
+
+# Padded row-pair pitch of the comparison layout (bioem_hip.hip, comparison_pitch: N a multiple of 128 from 256 pixels on,
+# Nyquist-split plans of the one-wave-per-comparison families): same arithmetic at other addresses -- the probability
+# block equals the unpadded layout's (BIOEM_NO_PITCH_PAD=1, read when the handle is created) BIT FOR BIT, through the
+# fused convolution (few particles) and the two-kernel one, for 11-, 21-, 27- and 41-row windows, and against the oracle
+@pytest.mark.parametrize("N,maxD,nP", [(256, 10, 4), (256, 5, 4), (256, 13, 4), (256, 20, 4), (256, 10, 300), (384, 10, 3)])
+def test_padded_pitch_equals_the_plain_layout_bit_for_bit(N, maxD, nP, monkeypatch):
+    from bioem_amd.synthetic import Workload
+    nO = 5
+    blocks = []
+    for pad in (True, False):
+        if not pad:
+            monkeypatch.setenv("BIOEM_NO_PITCH_PAD", "1")
+        W = Workload(N=N, nP=nP, nOrient=nO, nEnv=2, maxD=maxD, npts=300)
+        try:
+            raw, got = run_workload(W, 0, nO)
+            # (the hooks hand out the reference layout whatever the device layout is)
+            blocks.append(raw.tobytes() + W.engine.debug_convolution(nO - 1, 1)[0].tobytes() +
+                          W.engine.debug_particles()[0].tobytes())
+            if pad and nP <= 4:
+                sel = list(range(nP))
+                want, const = oracle_on_workload(W, sel, nO, 1)
+                assert_workload_matches(got, want, const, sel)
+        finally:
+            W.engine.close()
+    assert blocks[0] == blocks[1]
 
 
 # k_compare_wide2 (shared column transforms + row FFT) is picked from three 21-row tiles per axis on; forced here for
