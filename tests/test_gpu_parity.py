@@ -1244,13 +1244,15 @@ def test_fastm2_kernel_against_oracle(N, maxD, grid, algo):
         W.engine.close()
 
 
-def _random_configs(n, seed):
+def _random_configs(n, seed, sizes=None):
     """Seeded random (N, maxD, grid, algo, nEnv, nP, nO) tuples over the whole configuration space of the comparison
     kernels: every register-FFT length, the Nyquist split, window templates, row strides, tiles, the generic path."""
     rng = np.random.default_rng(seed)
     out = []
     while len(out) < n:
         N = int(rng.choice([int(rng.integers(8, 140)), int(rng.choice([32, 48, 64, 96, 128, 160, 192, 200, 224, 256]))]))
+        if sizes:                                  # (scripts/fuzz_configs.py --sizes: a fuzz of chosen image sizes)
+            N = int(rng.choice(sizes))
         grid = int(rng.choice([1, 1, 1, 2, 3, 4, 5]))
         maxD = int(rng.integers(0, max(1, N // 2 - 1)))
         if rng.random() < 0.5:
