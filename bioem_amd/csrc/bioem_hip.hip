@@ -990,16 +990,16 @@ static int create_impl(bioem_hip_handle *out, int device, const bioem_hip_param_
   }
   const int mD = maxD / h->gs;
   // Pitch of the comparison layout.  A lane block of the fast kernels keeps eight rows of one 64-column block in flight;
-  // with N a multiple of 64 a row pair is 16 B more than a multiple of 512 B (4 112 B at 512^2) and all of them start
-  // in the same few L2 channels.  Fifteen more words make the pitch an odd number of 256-byte lines (timing build,
-  // round 4: 512^2 8.3 -> 10.1 M/s, 384^2 17.8 -> 19.2, 256^2 40.1 -> 42.0; the real thing, same box: +20 / +6.7 / +3 % at
-  // +-5 and +-10 px, +1...6 % on the matrix-core families; 128^2 gains nothing and loses 1...3 % on few-particle jobs: not
-  // padded; 192^2 and 320^2 +-10 px -- an even number of lines + 16 B, two channel groups -- gain 2...3.5 %: padded).
-  // Those sizes are Nyquist-split plans of the one-wave-per-comparison families -- only their kernels read the
-  // pitch from the arguments (NYQ ? a.Hp : H); every other plan keeps Hp = H.
+  // with N a multiple of 64 a row pair is 16 B more than a multiple of 512 B (4 112 B at 512^2, 2 064 B at 256^2) and all
+  // of them start in the same few L2 channels.  Fifteen more words make the pitch an odd number of 256-byte lines
+  // (timing build first: 512^2 8.3 -> 10.1 M/s; the real thing, same box, +-5 / +-10 px: 512^2 +20 %, 384^2 +6.7 %, 448^2
+  // +7 / +4 %, 256^2 +3 %, 192^2 and 320^2 +2...3.5 %, +0...6 % on the matrix-core families; the headline shape, whose
+  // kernel reads one argument more, 54.74 against 54.68 M/s).  64^2 and 128^2 gain nothing, 128^2 loses 1...3 % on
+  // few-particle jobs: not padded.  k_compare_wide2 (operands once per comparison) gains nothing: its plans, the tiled
+  // ones, odd sizes and the direct kernel keep Hp = H.
   h->Hp = h->H;
   const bool directCC = getenv("BIOEM_CC_DIRECT") && atoi(getenv("BIOEM_CC_DIRECT")) != 0; // (its own kernels read conv)
-  if (h->nyq && h->fast && !h->wide2 && !h->rowsK && !h->tileT && !directCC && N % 64 == 0 && N >= 192 &&
+  if (h->fast && !h->wide2 && !h->rowsK && !h->tileT && !directCC && N % 64 == 0 && N >= 192 &&
       !getenv("BIOEM_NO_PITCH_PAD"))
     h->Hp = h->H + 15;
   h->Mc = (size_t) N * h->Hp;

@@ -410,7 +410,7 @@ __global__ __launch_bounds__(256, BIOEM_FAST_WAVES_PER_SIMD) void k_compare_fast
   const int oc_raw = ocg * 4 + wave;
   const bool oc_valid = oc_raw < a.nOC;
   const int oc = oc_valid ? oc_raw : a.nOC - 1;
-  const int Hp = NYQ ? a.Hp : H; // row-pair pitch in 16-byte words: padded for Nyquist-split plans only (bioem_hip.hip)
+  const int Hp = a.Hp; // row-pair pitch in 16-byte words (H, or H + 15: comparison_pitch in bioem_hip.hip)
   const size_t M = (size_t) N * Hp;
   // buffer descriptors built from wave-uniform values only (blockIdx / readfirstlane'd wave id)
   // timing-only ablation builds (never shipped): a zero-record descriptor drops the loads of one operand while

@@ -110,7 +110,7 @@ __global__ __launch_bounds__(256, 3) void k_compare_fastm2(const CompareArgs a)
   const int oc_raw = ocg * 4 + wave;
   const bool oc_valid = oc_raw < a.nOC;
   const int oc = oc_valid ? oc_raw : a.nOC - 1;
-  const int Hp = NYQ ? a.Hp : H; // row-pair pitch in 16-byte words: padded for Nyquist-split plans only (bioem_hip.hip)
+  const int Hp = a.Hp; // row-pair pitch in 16-byte words (H, or H + 15: comparison_pitch in bioem_hip.hip)
   const size_t M = (size_t) N * Hp;
   const auto rsrcF = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(const_cast<float2 *>(a.ref + (size_t) p * M)), 0,
                                                        (int) (M * sizeof(float2)), 0x00020000);

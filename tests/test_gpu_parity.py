@@ -1142,11 +1142,13 @@ def test_split_last_column_block_against_oracle(N, maxD, grid, algo, monkeypatch
 
 
 # Padded row-pair pitch of the comparison layout (bioem_hip.hip, comparison_pitch: N a multiple of 64 from 192 pixels on,
-# Nyquist-split plans of the one-wave-per-comparison families): same arithmetic at other addresses -- the probability
+# plans of the one-wave-per-comparison families): same arithmetic at other addresses -- the probability
 # block equals the unpadded layout's (BIOEM_NO_PITCH_PAD=1, read when the handle is created) BIT FOR BIT, through the
 # fused convolution (few particles) and the two-kernel one, for 11-, 21-, 27- and 41-row windows, and against the oracle
 @pytest.mark.parametrize("N,maxD,nP", [(256, 10, 4), (256, 5, 4), (256, 13, 4), (256, 20, 4), (256, 10, 300), (384, 10, 3),
-                                       (192, 10, 4), (192, 5, 4), (320, 10, 3)])
+                                       (192, 10, 4), (192, 5, 4), (320, 10, 3),
+                                       # ... and plans without the Nyquist split
+                                       (448, 10, 3), (320, 5, 3), (192, 13, 4), (320, 20, 3)])
 def test_padded_pitch_equals_the_plain_layout_bit_for_bit(N, maxD, nP, monkeypatch):
     from bioem_amd.synthetic import Workload
     nO = 5
