@@ -997,11 +997,13 @@ static int create_impl(bioem_hip_handle *out, int device, const bioem_hip_param_
   // kernel reads one argument more, 54.74 against 54.68 M/s).  64^2 and 128^2 gain nothing, 128^2 loses 1...3 % on
   // few-particle jobs: not padded.  k_compare_wide2 (operands once per comparison) gains nothing: its plans, the tiled
   // ones, odd sizes and the direct kernel keep Hp = H.
+  // (BIOEM_PITCH_PAD: another number of words.  7 / 15 / 23 / 31 / 47 are within 2 % of each other at 256^2 ... 512^2,
+  // profiles/r04_padded_pitch_ab.txt.)
   h->Hp = h->H;
   const bool directCC = getenv("BIOEM_CC_DIRECT") && atoi(getenv("BIOEM_CC_DIRECT")) != 0; // (its own kernels read conv)
   if (h->fast && !h->wide2 && !h->rowsK && !h->tileT && !directCC && N % 64 == 0 && N >= 192 &&
       !getenv("BIOEM_NO_PITCH_PAD"))
-    h->Hp = h->H + 15;
+    h->Hp = h->H + (getenv("BIOEM_PITCH_PAD") ? atoi(getenv("BIOEM_PITCH_PAD")) : 15);
   h->Mc = (size_t) N * h->Hp;
 
   // batch sizing: conv buffer <= ~96 MiB, partial buffer <= ~128 MiB
