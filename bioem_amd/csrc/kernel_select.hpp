@@ -24,7 +24,9 @@
 //   BIOEM_FAST_R=<len>    k_compare_fast with this register-FFT length only (sweeps)
 //   BIOEM_KEEP_WD5        11-row windows keep the 11-row template at every size
 // (run-time knobs outside the selection: BIOEM_PCHUNK, BIOEM_BATCH_ORIENTATIONS, BIOEM_FIXED_BATCH, BIOEM_NO_GROUP_XCD,
-//  BIOEM_COMPAT_RING, BIOEM_SERIAL_FOLD, BIOEM_SIGNATURE_LOG, BIOEM_HIP_LIBRARY (Python loader))
+//  BIOEM_COMPAT_RING, BIOEM_SERIAL_FOLD, BIOEM_SIGNATURE_LOG, BIOEM_HIP_LIBRARY (Python loader), BIOEM_NO_SPLIT_LAST (no
+//  half-wave split of a narrow last column block), BIOEM_NO_PITCH_PAD / BIOEM_PITCH_PAD=<words> (row-pair pitch of the
+//  comparison layout), BIOEM_MIN_BATCH_PAIRS, BIOEM_CONVOLVE_FUSED)
 #ifndef BIOEM_KERNEL_SELECT_HPP
 #define BIOEM_KERNEL_SELECT_HPP
 
