@@ -104,6 +104,7 @@ struct bioem_hip_ctx
   int gs = 1;                     // pixels per window row of the fast kernel (gcd of the displacement offsets)
   // wide windows (more than 31 offsets per axis): tilesPerAxis^2 launches of a tileT-row window (window_tiles.hpp)
   int genericWaves = 4; // waves per block of the generic kernel
+  int genericRows = 0;  // ... and its window rows per pass through the LDS (0 = all)
   bool rowsK = false;   // k_compare_rows / k_compare_oddfft (odd N) instead of the generic kernel
   int oddR = 0;         // k_compare_oddfft: register-FFT length (3, 5, 9, 15, 25) dividing an odd N; 0 = direct sums
   int tileT = 0, tilesPerAxis = 1;
@@ -516,6 +517,7 @@ int launch_compare_fold(bioem_hip_ctx *h, const BatchBuf &bb, int nOC, int orien
   else
   {
     const int gw = h->genericWaves;
+    a.ts = h->genericRows;
     const dim3 gridg((unsigned) ((size_t) ((nOC + gw - 1) / gw) * h->nMaps));
     hipLaunchKernelGGL(reinterpret_cast<fast_kernel_t>(const_cast<void *>(h->fn)), gridg, dim3(64 * gw), h->ldsBytes, h->stream, a);
   }
@@ -983,6 +985,7 @@ static int create_impl(bioem_hip_handle *out, int device, const bioem_hip_param_
     h->w2Halves = P.w2Halves;
     h->w2NW = P.w2NW;
     h->genericWaves = P.genericWaves;
+    h->genericRows = P.genericRows;
     h->fn = reinterpret_cast<const void *>(P.fn);
     h->ldsBytes = P.ldsBytes;
     HIP_CHECK(h, hipFuncSetAttribute(h->fn, hipFuncAttributeMaxDynamicSharedMemorySize,

@@ -11,6 +11,8 @@ namespace
 // One wave per comparison.  Column transform T[j][ky] = sum_kx X[kx][ky] w^(kx dx_j) by direct summation for the
 // nd displacement rows only: lane = frequency column, rows in chunks of 16 register accumulators, so X is formed
 // once per (kx, chunk) and each twiddle (uniform over the wave: one LDS broadcast read) feeds 64 columns.
+// The rows go through LDS in groups of a.ts (a multiple of the chunk; all nd where they fit): column transform of a
+// group, its posteriors, the next group -- the same work whatever the group size, and no window is too wide for the LDS.
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_compare_generic(const CompareArgs a)
 {
@@ -24,7 +26,8 @@ __global__ __launch_bounds__(256) void k_compare_generic(const CompareArgs a)
   const size_t dispBytes = ((size_t) nd * 4 + 255) & ~(size_t) 255; // displacement list, 256-byte granules
   float2 *Tall = reinterpret_cast<float2 *>(smem + (size_t) ((N + 2) & ~1) * 8 + dispBytes);
   const int wave = __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6)), lane = threadIdx.x & 63;
-  float2 *Tl = Tall + (size_t) wave * nd * Hs;
+  const int RG = a.ts > 0 && a.ts < nd ? a.ts : nd; // rows per group
+  float2 *Tl = Tall + (size_t) wave * RG * Hs;
   for (int t = threadIdx.x; t <= N; t += blockDim.x)
     twl[t] = a.tw[t];
   for (int t = threadIdx.x; t < nd; t += blockDim.x)
@@ -41,6 +44,16 @@ __global__ __launch_bounds__(256) void k_compare_generic(const CompareArgs a)
   const float2 *F = a.ref + (size_t) p * M;
   const float2 *C = a.conv + (size_t) oc * M;
 
+  const bioem_hip_param5 q = a.params[oc];
+  const double2 pc = a.postc[oc];
+  const double t2 = pc.x, prior = pc.y;
+  const float sumref = a.sumRef[p], sumsqref = a.sumsqRef[p];
+  const float nn = (float) (N * N);
+  Lse L;
+  lse_init(L);
+  for (int g0 = 0; g0 < nd; g0 += RG)
+  {
+  const int gEnd = min(nd, g0 + RG);
   for (int ky0 = 0; ky0 < H; ky0 += 64)
   {
     const int ky = ky0 + lane;
@@ -50,7 +63,7 @@ __global__ __launch_bounds__(256) void k_compare_generic(const CompareArgs a)
       wgt = 1.f;
     if (ky >= H)
       wgt = 0.f;
-    for (int j0 = 0; j0 < nd; j0 += CH)
+    for (int j0 = g0; j0 < gEnd; j0 += CH)
     {
       float tr[CH], ti[CH];
       int step[CH], idx[CH]; // wave-uniform (SGPRs): twiddle index of row j at the current kx
@@ -86,26 +99,20 @@ __global__ __launch_bounds__(256) void k_compare_generic(const CompareArgs a)
       {
 #pragma unroll
         for (int j = 0; j < CH; j++)
-          if (j0 + j < nd)
-            Tl[(size_t) (j0 + j) * Hs + ky] = make_float2(tr[j] * wgt, ti[j] * wgt);
+          if (j0 + j < gEnd)
+            Tl[(size_t) (j0 + j - g0) * Hs + ky] = make_float2(tr[j] * wgt, ti[j] * wgt);
       }
     }
   }
   __syncthreads();
 
-  const bioem_hip_param5 q = a.params[oc];
-  const double2 pc = a.postc[oc];
-  const double t2 = pc.x, prior = pc.y;
-  const float sumref = a.sumRef[p], sumsqref = a.sumsqRef[p];
-  const float nn = (float) (N * N);
-  Lse L;
-  lse_init(L);
-  for (int e = lane; e < nd * nd; e += 64)
+  for (int el = lane; el < (gEnd - g0) * nd; el += 64)
   {
+    const int e = g0 * nd + el; // visiting rank of the displacement
     const int ix = e / nd, iy = e - ix * nd;
     const int dy = displ[iy];
     const int step = dy < 0 ? dy + N : dy;
-    const float2 *row = Tl + (size_t) ix * Hs;
+    const float2 *row = Tl + (size_t) (ix - g0) * Hs;
     float acc = 0.f;
     int idx = 0;
     for (int ky = 0; ky < H; ky++)
@@ -120,6 +127,8 @@ __global__ __launch_bounds__(256) void k_compare_generic(const CompareArgs a)
     const float value = acc / nn;
     const double lp = logpro_eval(a.pd, q, value, sumref, sumsqref, t2, prior);
     lse_push(L, lp, e, value, a.algo);
+  }
+  __syncthreads(); // (the next group overwrites T)
   }
   lse_wave_reduce(L);
   if (lane == 0 && oc_valid)

@@ -99,11 +99,11 @@ fast_kernel_t find_kernel(int family, int a0 = 0, int a1 = 0, int a2 = 0, int a3
 // ------------------------------------------------------------------------------------------------
 // LDS budgets (bytes of dynamic shared memory per block)
 // ------------------------------------------------------------------------------------------------
-size_t compare_lds_bytes(int N, int H, int NW, int waves)
-{ // generic kernel: tables + per-wave T [nd rows][Hs]
+size_t compare_lds_bytes(int N, int H, int NW, int waves, int rows = 0)
+{ // generic kernel: tables + per-wave T [rows of a group][Hs] (rows = 0: all NW)
   const int Hs = (H + 1) & ~1;
   const size_t dispBytes = ((size_t) NW * 4 + 255) & ~(size_t) 255;
-  return (size_t) ((N + 2) & ~1) * 8 + dispBytes + (size_t) waves * NW * Hs * 8;
+  return (size_t) ((N + 2) & ~1) * 8 + dispBytes + (size_t) waves * (rows ? rows : NW) * Hs * 8;
 }
 #ifndef BIOEM_FAST_HALVES
 #define BIOEM_FAST_HALVES 0
@@ -143,6 +143,7 @@ struct KernelPlan
   std::vector<int> tileCenter, tileValid;
   int w2NRW = 0, w2NBLK = 0, w2TS = 0, w2Rows2 = 0, nyqWD = 0, w2Halves = 1, w2NW = 4;
   int genericWaves = 4;
+  int genericRows = 0; // k_compare_generic: window rows per pass through the LDS (0 = all)
   size_t ldsBytes = 0;
   fast_kernel_t fn = nullptr;
   const char *err = nullptr;
@@ -592,10 +593,21 @@ KernelPlan plan_kernels(int N, int maxD, int grid, int algo)
   P.fast = 0;
   P.N1 = 0;
   P.nyq = false;
+  // the window rows pass through the LDS in groups of whole register chunks (16 rows) where they do not fit at once --
+  // the same work, so the groups shrink before the block does (four waves share the particle's rows through L1)
   P.genericWaves = 4;
-  while (P.genericWaves > 1 && compare_lds_bytes(N, H, P.nd, P.genericWaves) > kLdsCU)
-    P.genericWaves >>= 1;
-  P.ldsBytes = compare_lds_bytes(N, H, P.nd, P.genericWaves);
+  P.genericRows = 0;
+  while (compare_lds_bytes(N, H, P.nd, P.genericWaves, P.genericRows) > kLdsCU)
+  {
+    const int rows = P.genericRows ? P.genericRows : P.nd;
+    if (rows > 16)
+      P.genericRows = std::max(16, (rows / 2 + 15) / 16 * 16);
+    else if (P.genericWaves > 1)
+      P.genericWaves >>= 1;
+    else
+      break;
+  }
+  P.ldsBytes = compare_lds_bytes(N, H, P.nd, P.genericWaves, P.genericRows);
   if (P.ldsBytes > kLdsCU)
     P.err = "configuration exceeds the 160 KiB LDS budget of the comparison kernel";
   return P;

@@ -1110,6 +1110,26 @@ def test_image_sizes_against_oracle(N, maxD, grid, fast, algo):
         W.engine.close()
 
 
+# k_compare_generic with a window whose T block does not fit the LDS at once (compare_generic.hpp: the rows pass through in
+# groups of whole 16-row chunks): displacement sets off the grid (maxD % grid != 0) and strides beyond 4 with 45...89 rows --
+# shapes that bioem_hip_create rejected before the end of round 4 ("exceeds the 160 KiB LDS budget"); an uneven last group,
+# odd N, both algorithms
+@pytest.mark.parametrize("N,maxD,grid,nP,nO", [(200, 98, 3, 3, 3), (225, 110, 5, 3, 2), (448, 220, 5, 2, 1),
+                                               (512, 162, 4, 2, 1)])
+@pytest.mark.parametrize("algo", [1, 2])
+def test_generic_kernel_windows_beyond_the_lds(N, maxD, grid, nP, nO, algo):
+    from bioem_amd.synthetic import Workload
+    W = Workload(N=N, nP=nP, nOrient=nO, nEnv=1, maxD=maxD, grid=grid, algo=algo, npts=200)
+    try:
+        assert W.engine.kernel_signature == "k_compare_generic"
+        sel = list(range(nP))
+        want, const = oracle_on_workload(W, sel, nO, algo)
+        _, got = run_workload(W, 0, nO)
+        assert_workload_matches(got, want, const, sel)
+    finally:
+        W.engine.close()
+
+
 # k_compare_fast with a last column block of at most 32 columns: its half-waves share the columns, the low half the first
 # ceil(N1 / 2) k1 steps, the high half the rest (compare_fast.hpp).  One block only (60), two (144...190), three (288,
 # 300), even and odd N1 (160 = 10 x 16, 144 = 9 x 16, 150 = 15 x 10, 190 = 19 x 10), 11- and 21-row windows, a coarse grid
